@@ -1,0 +1,88 @@
+"""ctypes binding of libmsnap.so (include/msnap.h).
+
+The shared library is the product: when it is missing or cannot be loaded this
+module raises -- there is no CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmsnap.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# symbol -> (restype, argtypes); mirrors include/msnap.h one to one
+_VP = ctypes.c_void_p
+_I = ctypes.c_int
+_D = ctypes.c_double
+SIGNATURES = {
+    "msnap_version": (_I, []),
+    "msnap_strerror": (ctypes.c_char_p, [_I]),
+    "msnap_last_hip_error": (ctypes.c_char_p, [_VP]),
+    "msnap_create": (_I, [c_void_pp, _I, _I, _I]),
+    "msnap_destroy": (None, [_VP]),
+    "msnap_set_stream": (_I, [_VP, _VP]),
+    "msnap_get_stream": (_VP, [_VP]),
+    "msnap_sync": (_I, [_VP]),
+    "msnap_timer_start": (_I, [_VP]),
+    "msnap_timer_stop": (_I, [_VP, c_float_p]),
+    "msnap_solve_batch": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
+    "msnap_solve_batch_device": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
+    "msnap_pack_pol_matrix": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "msnap_pack_pol_matrix_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "msnap_formation_transform": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "msnap_formation_transform_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "msnap_sample": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _I, _VP]),
+    "msnap_sample_device": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _I, _VP]),
+    "msnap_formation_collide": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
+    "msnap_formation_collide_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
+    "msnap_mesh_sweep": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
+    "msnap_mesh_sweep_device": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
+}
+
+
+class MsnapError(RuntimeError):
+    """A libmsnap entry point returned a negative msnap_error."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"msnap error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Load libmsnap.so once.  Raises OSError with build instructions if absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise OSError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C drone_path_planning_python_amd/csrc` (hipcc, gfx950). "
+                "There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the ABI drifted
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def check(lib, ctx_handle, rc: int) -> None:
+    if rc == 0:
+        return
+    msg = lib.msnap_strerror(rc).decode()
+    if rc == -2 and ctx_handle:
+        msg += ": " + lib.msnap_last_hip_error(ctx_handle).decode()
+    raise MsnapError(rc, msg)

@@ -1,0 +1,231 @@
+"""Context: the Python face of one msnap_ctx (one GPU, one HIP stream).
+
+Host entry points take / return NumPy arrays (the library stages them through
+device buffers).  ``*_device`` entry points take objects exposing
+``data_ptr()`` (torch CUDA tensors) and are asynchronous on the context's
+stream; torch is plumbing for device memory only and is imported lazily.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+
+ST_OK, ST_SINGULAR, ST_TIMES, ST_NONFINITE = 0, 1, 2, 3
+STATUS_TEXT = {
+    ST_OK: "ok",
+    ST_SINGULAR: "singular system",
+    ST_TIMES: "times not strictly increasing",
+    ST_NONFINITE: "non-finite waypoint or time",
+}
+
+
+def _ptr(x):
+    """Device pointer of a torch tensor (or a raw int address)."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return ctypes.c_void_p(x)
+    return ctypes.c_void_p(x.data_ptr())
+
+
+def _host(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """One msnap context (include/msnap.h: msnap_create / msnap_destroy)."""
+
+    def __init__(self, device_id: int = 0, order: int = 7, max_segments: int = 256):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self._lock = threading.Lock()   # a context is not re-entrant (msnap.h)
+        rc = self._lib.msnap_create(ctypes.byref(self._h), int(device_id), int(order), int(max_segments))
+        if rc != 0:
+            self._h = ctypes.c_void_p()
+            _lib.check(self._lib, None, rc)
+        self.device_id = int(device_id)
+        self.order = int(order)
+        self.ncoef = self.order + 1
+        self.max_segments = int(max_segments)
+
+    # ---- lifetime -------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.msnap_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        _lib.check(self._lib, self._h, rc)
+
+    # ---- stream / timing ------------------------------------------------------
+    def set_stream(self, hip_stream: int | None):
+        with self._lock:
+            self._ck(self._lib.msnap_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def stream(self) -> int:
+        return int(self._lib.msnap_get_stream(self._h) or 0)
+
+    def sync(self):
+        with self._lock:
+            self._ck(self._lib.msnap_sync(self._h))
+
+    def timer_start(self):
+        self._ck(self._lib.msnap_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float()
+        self._ck(self._lib.msnap_timer_stop(self._h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    # ---- a1/a2 solve ----------------------------------------------------------
+    def solve_batch(self, wp, t):
+        """wp [N, m, 4], t [N, m] or shared [m] (host) ->
+        coef [N, M, 4, ncoef], dur [N, M], status [N] int32."""
+        wp, pwp = _host(wp, np.float64)
+        t, pt = _host(t, np.float64)
+        if wp.ndim != 3 or wp.shape[2] != 4:
+            raise ValueError("wp must be [N, m, 4]")
+        N, m, _ = wp.shape
+        shared = int(t.ndim == 1)
+        if (shared and t.shape != (m,)) or (not shared and t.shape != (N, m)):
+            raise ValueError("t must be [N, m] or [m]")
+        M = m - 1
+        coef = np.empty((N, max(M, 0), 4, self.ncoef), dtype=np.float64)
+        dur = np.empty((N, max(M, 0)), dtype=np.float64)
+        status = np.empty((N,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_solve_batch(
+                self._h, N, M, pwp, pt, shared, coef.ctypes.data_as(ctypes.c_void_p),
+                dur.ctypes.data_as(ctypes.c_void_p), status.ctypes.data_as(ctypes.c_void_p)))
+        return coef, dur, status
+
+    def solve_batch_device(self, n_drones, n_seg, wp, t, shared_times, coef, dur, status):
+        with self._lock:
+            self._ck(self._lib.msnap_solve_batch_device(
+                self._h, int(n_drones), int(n_seg), _ptr(wp), _ptr(t), int(bool(shared_times)),
+                _ptr(coef), _ptr(dur), _ptr(status)))
+
+    # ---- a7 pack ---------------------------------------------------------------
+    def pack_pol_matrix(self, coef, dur):
+        coef, pc = _host(coef, np.float64)
+        dur, pd = _host(dur, np.float64)
+        N, M = dur.shape
+        out = np.empty((N, M, 1 + 4 * self.ncoef), dtype=np.float32)
+        with self._lock:
+            self._ck(self._lib.msnap_pack_pol_matrix(self._h, N, M, pc, pd, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def pack_pol_matrix_device(self, n_drones, n_seg, coef, dur, out):
+        with self._lock:
+            self._ck(self._lib.msnap_pack_pol_matrix_device(self._h, int(n_drones), int(n_seg), _ptr(coef),
+                                                           _ptr(dur), _ptr(out)))
+
+    # ---- a8 formation transform -----------------------------------------------
+    def formation_transform(self, rb_pose, offsets):
+        rb, prb = _host(rb_pose, np.float64)
+        off, poff = _host(offsets, np.float64)
+        if rb.ndim != 2 or rb.shape[1] != 7 or off.ndim != 2 or off.shape[1] != 3:
+            raise ValueError("rb_pose must be [P, 7], offsets [K, 3]")
+        P, K = rb.shape[0], off.shape[0]
+        out = np.empty((K, P, 7), dtype=np.float64)
+        with self._lock:
+            self._ck(self._lib.msnap_formation_transform(self._h, P, K, prb, poff,
+                                                        out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def formation_transform_device(self, n_poses, n_offsets, rb_pose, offsets, out):
+        with self._lock:
+            self._ck(self._lib.msnap_formation_transform_device(self._h, int(n_poses), int(n_offsets),
+                                                               _ptr(rb_pose), _ptr(offsets), _ptr(out)))
+
+    # ---- a5 sampler ------------------------------------------------------------
+    def sample(self, coef, dur, dt: float, n_samples: int, n_axes: int = 3):
+        coef, pc = _host(coef, np.float64)
+        dur, pd = _host(dur, np.float64)
+        N, M = dur.shape
+        pos = np.empty((N, int(n_samples), int(n_axes)), dtype=np.float64)
+        with self._lock:
+            self._ck(self._lib.msnap_sample(self._h, N, M, pc, pd, float(dt), int(n_samples), int(n_axes),
+                                           pos.ctypes.data_as(ctypes.c_void_p)))
+        return pos
+
+    def sample_device(self, n_drones, n_seg, coef, dur, dt, n_samples, n_axes, pos):
+        with self._lock:
+            self._ck(self._lib.msnap_sample_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
+                                                  float(dt), int(n_samples), int(n_axes), _ptr(pos)))
+
+    # ---- collision passes --------------------------------------------------------
+    def formation_collide(self, pos_rows, pos_cols, radius: float, row_offset: int = 0):
+        pr, ppr = _host(pos_rows, np.float64)
+        pc, ppc = _host(pos_cols, np.float64)
+        R, S, _ = pr.shape
+        Cn = pc.shape[0]
+        if pc.shape[1:] != (S, 3) or pr.shape[2] != 3:
+            raise ValueError("pos_rows [R,S,3] and pos_cols [C,S,3] must share S")
+        md = np.empty((R,), dtype=np.float64)
+        partner = np.empty((R,), dtype=np.int32)
+        hit = np.empty((R,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide(
+                self._h, R, int(row_offset), Cn, S, ppr, ppc, float(radius),
+                md.ctypes.data_as(ctypes.c_void_p), partner.ctypes.data_as(ctypes.c_void_p),
+                hit.ctypes.data_as(ctypes.c_void_p)))
+        return md, partner, hit.astype(bool)
+
+    def formation_collide_device(self, n_rows, row_offset, n_cols, n_samples, pos_rows, pos_cols, radius,
+                                 min_dist, partner, hit):
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_device(
+                self._h, int(n_rows), int(row_offset), int(n_cols), int(n_samples), _ptr(pos_rows),
+                _ptr(pos_cols), float(radius), _ptr(min_dist), _ptr(partner), _ptr(hit)))
+
+    def mesh_sweep(self, pos, tris, radius: float):
+        p, pp = _host(pos, np.float64)
+        tr, ptr_ = _host(tris, np.float64)
+        N, S, _ = p.shape
+        Tn = tr.shape[0]
+        md = np.empty((N,), dtype=np.float64)
+        hit = np.empty((N,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_mesh_sweep(self._h, N, S, pp, Tn, ptr_, float(radius),
+                                               md.ctypes.data_as(ctypes.c_void_p),
+                                               hit.ctypes.data_as(ctypes.c_void_p)))
+        return md, hit.astype(bool)
+
+    def mesh_sweep_device(self, n_drones, n_samples, pos, n_tris, tris, radius, min_dist, hit):
+        with self._lock:
+            self._ck(self._lib.msnap_mesh_sweep_device(self._h, int(n_drones), int(n_samples), _ptr(pos),
+                                                      int(n_tris), _ptr(tris), float(radius), _ptr(min_dist),
+                                                      _ptr(hit)))
+
+
+_default = {}
+_default_lock = threading.Lock()
+
+
+def default_context(order: int = 7, device_id: int = 0) -> Context:
+    """Process-wide context per (device, order), created on first use."""
+    key = (int(device_id), int(order))
+    with _default_lock:
+        ctx = _default.get(key)
+        if ctx is None:
+            ctx = Context(device_id=device_id, order=order, max_segments=4096)
+            _default[key] = ctx
+        return ctx

@@ -1,0 +1,373 @@
+// Kernels either side of the solve: the float32 pol-matrix pack (a7), the
+// formation transform (a8), the piecewise sampler (a5) and the two collision
+// passes (new capability).  gfx950, wave64.
+#include <math.h>
+
+#include "msnap_internal.h"
+
+namespace msnap {
+
+// ------------------------------------------------------------------------------------
+// a7: matrix[M][1 + 4*ncoef] float32 = [T | x | y | z | yaw]
+// (reference scripts/drones_pols_generator.py:63-77)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pack_kernel(const double *__restrict__ coef, const double *__restrict__ dur, float *__restrict__ out,
+            size_t n_rows /* N*M */, int nc) {
+  const int ncol = 1 + 4 * nc;
+  const size_t total = n_rows * (size_t)ncol;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = idx / ncol;
+    const int col = (int)(idx - row * ncol);
+    const double v = (col == 0) ? dur[row] : coef[row * (size_t)(4 * nc) + (col - 1)];
+    out[idx] = (float)v;
+  }
+}
+
+int launch_pack(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, float *out) {
+  const size_t rows = (size_t)n_drones * n_seg;
+  const int nc = ctx->order + 1;
+  const size_t total = rows * (1 + 4 * nc);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)ctx->n_cu * 8) blocks = (size_t)ctx->n_cu * 8;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, out, rows, nc);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// a8: p' = R(q_rb) p_k + t_rb ;  q' = quaternion of R(q_rb)
+// (reference scripts/drones_traj_generator.py:67-82 through tf2_geometry_msgs
+// do_transform_pose -> PyKDL Frame product; KDL is not vendored in the
+// reference: Rotation::Quaternion / Rotation::GetQuaternion restated from the
+// published orocos_kdl frames.cpp.  The drone poses carry identity orientation,
+// drones_traj_generator.py:31,38.)
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+formation_kernel(const double *__restrict__ rb, const double *__restrict__ off, double *__restrict__ out,
+                 int P, int Kn) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)P * Kn;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / P);
+    const int p = (int)(idx - (size_t)k * P);
+    const double *r = rb + (size_t)p * 7;
+    const double tx = r[0], ty = r[1], tz = r[2];
+    const double x = r[3], y = r[4], z = r[5], w = r[6];
+    const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    const double m00 = w2 + x2 - y2 - z2, m01 = 2 * x * y - 2 * w * z, m02 = 2 * x * z + 2 * w * y;
+    const double m10 = 2 * x * y + 2 * w * z, m11 = w2 - x2 + y2 - z2, m12 = 2 * y * z - 2 * w * x;
+    const double m20 = 2 * x * z - 2 * w * y, m21 = 2 * y * z + 2 * w * x, m22 = w2 - x2 - y2 + z2;
+    const double ox = off[k * 3 + 0], oy = off[k * 3 + 1], oz = off[k * 3 + 2];
+    double *o = out + idx * 7;
+    o[0] = m00 * ox + m01 * oy + m02 * oz + tx;
+    o[1] = m10 * ox + m11 * oy + m12 * oz + ty;
+    o[2] = m20 * ox + m21 * oy + m22 * oz + tz;
+    // Rotation::GetQuaternion
+    const double trace = m00 + m11 + m22;
+    double qx, qy, qz, qw;
+    if (trace > 1e-12) {
+      const double s = 0.5 / sqrt(trace + 1.0);
+      qw = 0.25 / s;
+      qx = (m21 - m12) * s;
+      qy = (m02 - m20) * s;
+      qz = (m10 - m01) * s;
+    } else if (m00 > m11 && m00 > m22) {
+      const double s = 2.0 * sqrt(1.0 + m00 - m11 - m22);
+      qw = (m21 - m12) / s;
+      qx = 0.25 * s;
+      qy = (m01 + m10) / s;
+      qz = (m02 + m20) / s;
+    } else if (m11 > m22) {
+      const double s = 2.0 * sqrt(1.0 + m11 - m00 - m22);
+      qw = (m02 - m20) / s;
+      qx = (m01 + m10) / s;
+      qy = 0.25 * s;
+      qz = (m12 + m21) / s;
+    } else {
+      const double s = 2.0 * sqrt(1.0 + m22 - m00 - m11);
+      qw = (m10 - m01) / s;
+      qx = (m02 + m20) / s;
+      qy = (m12 + m21) / s;
+      qz = 0.25 * s;
+    }
+    o[3] = qx;
+    o[4] = qy;
+    o[5] = qz;
+    o[6] = qw;
+  }
+}
+
+int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const double *rb_pose,
+                               const double *offsets, double *out) {
+  const size_t total = (size_t)n_poses * n_offsets;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)ctx->n_cu * 8) blocks = (size_t)ctx->n_cu * 8;
+  hipLaunchKernelGGL(formation_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, rb_pose, offsets,
+                     out, n_poses, n_offsets);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// a5: PiecewisePolynomial.eval on the grid t = s*dt
+// (reference src/optimizations/uav_trajectory.py:154-169: strict '<' lookup,
+// running sum of durations, last piece extrapolates; Horner of :17-22 with
+// separate multiply and add, hence fp contract off for bit parity)
+// ------------------------------------------------------------------------------------
+template <int NC>
+__global__ void __launch_bounds__(256)
+sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
+              int naxes, double *__restrict__ pos) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)N * S;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx / S);
+    const int s = (int)(idx - (size_t)d * S);
+    const double t = (double)s * dt;
+    const double *dr = dur + (size_t)d * M;
+    double acc = 0.0;
+    int seg = M - 1;
+    bool found = false;
+    for (int i = 0; i < M; ++i) {
+      const double Ti = dr[i];
+      if (!found && t < acc + Ti) {
+        seg = i;
+        found = true;
+      }
+      if (!found && i < M - 1) acc = acc + Ti;
+    }
+    // not found: acc == sum(dur[:-1]) and seg == M-1 (uav_trajectory.py:161-163)
+    const double tl = t - acc;
+    const double *c = coef + ((size_t)d * M + seg) * 4 * NC;
+    for (int a = 0; a < naxes; ++a) {
+      double x = 0.0;
+#pragma unroll
+      for (int q = NC - 1; q >= 0; --q) x = x * tl + c[a * NC + q];
+      pos[idx * naxes + a] = x;
+    }
+  }
+}
+
+int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
+                  int n_samples, int n_axes, double *pos) {
+  const size_t total = (size_t)n_drones * n_samples;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)ctx->n_cu * 16) blocks = (size_t)ctx->n_cu * 16;
+  if (ctx->order == 7)
+    hipLaunchKernelGGL((sample_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
+                       n_drones, n_seg, n_samples, n_axes, pos);
+  else
+    hipLaunchKernelGGL((sample_kernel<10>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
+                       n_drones, n_seg, n_samples, n_axes, pos);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Formation pass: for every owned drone i the minimum over all other drones j and
+// all common samples s of |p_i(s) - p_j(s)|.  One lane per row drone; the column
+// drone is wave-uniform, so its samples come through the scalar cache.  The
+// column range is sliced over blockIdx.y; a second tiny kernel merges slices.
+// Semantics are this repo's: no reference implementation exists.
+// ------------------------------------------------------------------------------------
+constexpr int kSampleChunk = 8;
+
+__global__ void __launch_bounds__(kWave)
+collide_partial_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int row_offset,
+                       int Cn, int S, int cols_per_slice, double *__restrict__ part_d2,
+                       int32_t *__restrict__ part_j) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x;
+  const int r_raw = blockIdx.x * kWave + lane;
+  const bool live = r_raw < R;
+  const int r = live ? r_raw : R - 1;
+  const int grow = row_offset + r;
+  const int c0 = blockIdx.y * cols_per_slice;
+  int c1 = c0 + cols_per_slice;
+  if (c1 > Cn) c1 = Cn;
+  double best = INFINITY;
+  int bestj = -1;
+  const double *pr = prow + (size_t)r * S * 3;
+  for (int s0 = 0; s0 < S; s0 += kSampleChunk) {
+    const int ns = (S - s0 < kSampleChunk) ? (S - s0) : kSampleChunk;
+    double rx[kSampleChunk], ry[kSampleChunk], rz[kSampleChunk];
+#pragma unroll
+    for (int q = 0; q < kSampleChunk; ++q) {
+      const int sq = (q < ns) ? (s0 + q) : s0;  // tail repeats a valid sample (min unaffected)
+      rx[q] = pr[(size_t)sq * 3 + 0];
+      ry[q] = pr[(size_t)sq * 3 + 1];
+      rz[q] = pr[(size_t)sq * 3 + 2];
+    }
+    for (int j = c0; j < c1; ++j) {
+      const double *pc = pcol + (size_t)j * S * 3;
+      double m = INFINITY;
+#pragma unroll
+      for (int q = 0; q < kSampleChunk; ++q) {
+        const int sq = (q < ns) ? (s0 + q) : s0;
+        const double dx = pc[(size_t)sq * 3 + 0] - rx[q];
+        const double dy = pc[(size_t)sq * 3 + 1] - ry[q];
+        const double dz = pc[(size_t)sq * 3 + 2] - rz[q];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        m = (d2 < m) ? d2 : m;
+      }
+      if (j == grow) m = INFINITY;
+      if (m < best || (m == best && j < bestj)) {
+        best = m;
+        bestj = j;
+      }
+    }
+  }
+  if (live) {
+    part_d2[(size_t)blockIdx.y * R + r] = best;
+    part_j[(size_t)blockIdx.y * R + r] = (best == INFINITY) ? -1 : bestj;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, int R, int nsl,
+                     double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
+                     int32_t *__restrict__ hit) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  double best = INFINITY;
+  int bj = -1;
+  for (int s = 0; s < nsl; ++s) {
+    const double v = part_d2[(size_t)s * R + r];
+    const int j = part_j[(size_t)s * R + r];
+    if (j >= 0 && (v < best || (v == best && j < bj))) {
+      best = v;
+      bj = j;
+    }
+  }
+  const double dist = sqrt(best);
+  min_dist[r] = dist;
+  partner[r] = bj;
+  hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+}
+
+int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
+                             const double *pos_rows, const double *pos_cols, double radius, double *min_dist,
+                             int32_t *partner, int32_t *hit) {
+  const int rowblocks = (n_rows + kWave - 1) / kWave;
+  int nsl = (ctx->n_cu * 16 + rowblocks - 1) / rowblocks;
+  const int max_sl = (n_cols + 31) / 32;
+  if (nsl > max_sl) nsl = max_sl;
+  if (nsl < 1) nsl = 1;
+  if (nsl > 65535) nsl = 65535;
+  const int cps = (n_cols + nsl - 1) / nsl > 0 ? (n_cols + nsl - 1) / nsl : 1;
+  const size_t wbytes = (size_t)nsl * n_rows * (sizeof(double) + sizeof(int32_t));
+  int rc = ensure(ctx, ctx->stage[7], wbytes);
+  if (rc) return rc;
+  double *pd = (double *)ctx->stage[7].p;
+  int32_t *pj = (int32_t *)(pd + (size_t)nsl * n_rows);
+  hipLaunchKernelGGL(collide_partial_kernel, dim3(rowblocks, nsl), dim3(kWave), 0, ctx->stream, pos_rows,
+                     pos_cols, n_rows, row_offset, n_cols, n_samples, cps, pd, pj);
+  MSNAP_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, pd, pj,
+                     n_rows, nsl, radius, min_dist, partner, hit);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Mesh sweep: min over samples and triangles of the point-triangle distance
+// (closest-point regions, Ericson 5.1.5).  One wavefront per drone, lanes stride
+// the samples; the triangle is wave-uniform (scalar loads).  Semantics are this
+// repo's; the reference only has a boolean FCL mesh-mesh test in the
+// planner (src/RigidBodyPlanners/fcl_checker.py:93-100).
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double pt_tri_d2(double px, double py, double pz, const double *__restrict__ t) {
+#pragma clang fp contract(off)
+  const double ax = t[0], ay = t[1], az = t[2];
+  const double bx = t[3], by = t[4], bz = t[5];
+  const double cx = t[6], cy = t[7], cz = t[8];
+  const double abx = bx - ax, aby = by - ay, abz = bz - az;
+  const double acx = cx - ax, acy = cy - ay, acz = cz - az;
+  const double apx = px - ax, apy = py - ay, apz = pz - az;
+  const double d1 = abx * apx + aby * apy + abz * apz;
+  const double d2 = acx * apx + acy * apy + acz * apz;
+  double qx, qy, qz;
+  if (d1 <= 0.0 && d2 <= 0.0) {
+    qx = ax; qy = ay; qz = az;
+  } else {
+    const double bpx = px - bx, bpy = py - by, bpz = pz - bz;
+    const double d3 = abx * bpx + aby * bpy + abz * bpz;
+    const double d4 = acx * bpx + acy * bpy + acz * bpz;
+    if (d3 >= 0.0 && d4 <= d3) {
+      qx = bx; qy = by; qz = bz;
+    } else {
+      const double vc = d1 * d4 - d3 * d2;
+      if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double v = d1 / (d1 - d3);
+        qx = ax + v * abx; qy = ay + v * aby; qz = az + v * abz;
+      } else {
+        const double cpx = px - cx, cpy = py - cy, cpz = pz - cz;
+        const double d5 = abx * cpx + aby * cpy + abz * cpz;
+        const double d6 = acx * cpx + acy * cpy + acz * cpz;
+        if (d6 >= 0.0 && d5 <= d6) {
+          qx = cx; qy = cy; qz = cz;
+        } else {
+          const double vb = d5 * d2 - d1 * d6;
+          if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+            const double w = d2 / (d2 - d6);
+            qx = ax + w * acx; qy = ay + w * acy; qz = az + w * acz;
+          } else {
+            const double va = d3 * d6 - d5 * d4;
+            if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+              const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+              qx = bx + w * (cx - bx); qy = by + w * (cy - by); qz = bz + w * (cz - bz);
+            } else {
+              const double denom = 1.0 / (va + vb + vc);
+              const double v = vb * denom, w = vc * denom;
+              qx = ax + abx * v + acx * w;
+              qy = ay + aby * v + acy * w;
+              qz = az + abz * v + acz * w;
+            }
+          }
+        }
+      }
+    }
+  }
+  const double ex = px - qx, ey = py - qy, ez = pz - qz;
+  return ex * ex + ey * ey + ez * ez;
+}
+
+__global__ void __launch_bounds__(kWave)
+mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__restrict__ tris, int n_tris,
+                  double radius, double *__restrict__ min_dist, int32_t *__restrict__ hit) {
+  const int d = blockIdx.x;
+  const int lane = threadIdx.x;
+  double best = INFINITY;
+  for (int s = lane; s < S; s += kWave) {
+    const double *p = pos + ((size_t)d * S + s) * 3;
+    const double px = p[0], py = p[1], pz = p[2];
+    for (int t = 0; t < n_tris; ++t) {
+      const double v = pt_tri_d2(px, py, pz, tris + (size_t)t * 9);
+      best = (v < best) ? v : best;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double other = __shfl_xor(best, o);
+    best = (other < best) ? other : best;
+  }
+  if (lane == 0) {
+    const double dist = sqrt(best);
+    min_dist[d] = dist;
+    hit[d] = (dist < radius) ? 1 : 0;
+  }
+}
+
+int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
+                      const double *tris, double radius, double *min_dist, int32_t *hit) {
+  hipLaunchKernelGGL(mesh_sweep_kernel, dim3(n_drones), dim3(kWave), 0, ctx->stream, pos, n_drones, n_samples,
+                     tris, n_tris, radius, min_dist, hit);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+}  // namespace msnap

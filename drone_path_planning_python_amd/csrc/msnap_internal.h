@@ -1,0 +1,77 @@
+// Internal declarations shared by the translation units of libmsnap.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/msnap.h"
+
+#define MSNAP_VERSION_NUM 100  /* 0.1.0 */
+
+namespace msnap {
+
+constexpr int kWave = 64;
+constexpr int kAxes = 4;                // x, y, z, yaw: one lane each
+constexpr int kDronesPerWave = 16;      // 16 drones x 4 axis-lanes = one wavefront
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+// number of scratch doubles one 16-drone tile needs in the K1 solve
+// (waypoint stash, T, 1/T, G_i blocks, z_i vectors) -- see msnap_solve.hip
+inline size_t solve_scratch_words(int khalf, int n_seg) {
+  const size_t nu = (size_t)khalf - 1;
+  const size_t M = (size_t)n_seg;
+  const size_t knots = M > 0 ? M - 1 : 0;
+  return 64 * (M + 1) + 16 * M * 2 + 16 * nu * nu * knots + 64 * nu * knots;
+}
+
+// growable device buffer
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace msnap
+
+struct msnap_ctx {
+  int device = 0;
+  int order = 7;
+  int khalf = 4;           // (order+1)/2
+  int max_segments = 0;
+  int n_cu = 256;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  msnap::DevBuf scratch;   // global-memory scratch for n_seg too large for LDS
+  msnap::DevBuf stage[8];  // device staging for the host-pointer entry points
+  char hip_err[256] = {0};
+};
+
+namespace msnap {
+
+int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what);
+int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes);
+
+#define MSNAP_HIP(ctx, call)                                         \
+  do {                                                               \
+    hipError_t e__ = (call);                                         \
+    if (e__ != hipSuccess) return msnap::record_hip_error(ctx, e__, #call); \
+  } while (0)
+
+// kernel launchers (device pointers, asynchronous on ctx->stream)
+int launch_solve(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, const double *t,
+                 int shared_times, double *coef, double *dur, int32_t *status);
+int launch_pack(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                float *out);
+int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const double *rb_pose,
+                               const double *offsets, double *out);
+int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                  double dt, int n_samples, int n_axes, double *pos);
+int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
+                             const double *pos_rows, const double *pos_cols, double radius,
+                             double *min_dist, int32_t *partner, int32_t *hit);
+int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
+                      const double *tris, double radius, double *min_dist, int32_t *hit);
+int solve_kernel_setup(msnap_ctx *ctx);
+
+}  // namespace msnap

@@ -1,0 +1,154 @@
+/* msnap.h -- C-ABI of the MI355X-native minimum-snap trajectory hot path.
+ *
+ * The reference (mjmyt/drone_path_planning_python) has no FFI: its de-facto
+ * boundary for this path is the Python call
+ *     calculate_trajectory4D(waypoints)      src/optimizations/__init__.py:2,
+ *                                            src/optimizations/calculatingTrajectories.py:200-213
+ * invoked from scripts/drones_pols_generator.py:58.  Every entry point below
+ * names the reference interface it replaces.  Plain pointers and sizes only;
+ * no torch / numpy types cross this boundary.
+ *
+ * Conventions
+ *   - all arrays row-major, caller-owned, fp64 unless noted;
+ *   - entry points WITHOUT a suffix take HOST pointers (staged through the
+ *     context's pinned buffers, synchronous);
+ *   - entry points ending in _device take DEVICE pointers, are asynchronous on
+ *     the context's stream (msnap_sync / stream order to observe results);
+ *   - order = polynomial degree, 7 (minimum snap, the reference) or 9
+ *     (minimum crackle, BASELINE.json configs[4]; no reference exists);
+ *     ncoef = order + 1; coefficients are in ASCENDING powers (c_k t^k), the
+ *     reference's Polynomial.p layout (src/optimizations/uav_trajectory.py:17-22);
+ *   - functions return 0 or a negative msnap_error; they never throw or abort.
+ *     Per-drone problems are reported in status[] (the reference raises
+ *     numpy.linalg.LinAlgError / AssertionError out of the ROS callback instead).
+ *   - a context is not re-entrant: serialise calls per context (the Python
+ *     wrapper holds a lock; rospy runs callback1/callback2 on separate threads,
+ *     scripts/drones_pols_generator.py:102-103).  Contexts are independent.
+ */
+#ifndef MSNAP_H
+#define MSNAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msnap_ctx msnap_ctx;
+
+enum msnap_error {
+  MSNAP_OK = 0,
+  MSNAP_EINVAL = -1,      /* null pointer / negative size / bad flag          */
+  MSNAP_EHIP = -2,        /* a HIP runtime call failed (msnap_last_hip_error) */
+  MSNAP_EORDER = -3,      /* order is not 7 or 9                              */
+  MSNAP_ESEGMENTS = -4,   /* n_seg < 1 or n_seg > max_segments of the context */
+  MSNAP_ENOMEM = -5,      /* host or device allocation failed                 */
+  MSNAP_ENODEVICE = -6    /* no gfx950 device / device_id out of range        */
+};
+
+enum msnap_status {       /* per-drone, written to status[]                   */
+  MSNAP_ST_OK = 0,
+  MSNAP_ST_SINGULAR = 1,  /* a pivot of the block LDL^T was <= 0 or not finite */
+  MSNAP_ST_TIMES = 2,     /* times not strictly increasing (or t[1] <= 2 t[0]) */
+  MSNAP_ST_NONFINITE = 3  /* NaN / Inf in the waypoints or times               */
+};
+
+int msnap_version(void);                       /* 10000*major + 100*minor + patch */
+const char *msnap_strerror(int code);
+const char *msnap_last_hip_error(const msnap_ctx *ctx);
+
+/* One HIP stream + pinned/device scratch per context. */
+int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments);
+void msnap_destroy(msnap_ctx *ctx);
+/* Borrow an external hipStream_t (e.g. torch's current stream); NULL restores
+ * the context's own stream. */
+int msnap_set_stream(msnap_ctx *ctx, void *hip_stream);
+void *msnap_get_stream(msnap_ctx *ctx);
+int msnap_sync(msnap_ctx *ctx);
+/* hipEvent timing on the context's stream (bench.py roofline leg). */
+int msnap_timer_start(msnap_ctx *ctx);
+int msnap_timer_stop(msnap_ctx *ctx, float *elapsed_ms);   /* synchronises */
+
+/* ---- a1/a2: calculate_trajectory1D / calculate_trajectory4D, batched ----------
+ * replaces src/optimizations/calculatingTrajectories.py:37-197 (per axis) and
+ * :200-213 (4 axes) for n_drones independent trajectories.
+ *   wp     [n_drones][n_seg+1][4]   x, y, z, yaw per waypoint
+ *   t      [n_drones][n_seg+1] absolute times, or [n_seg+1] if shared_times != 0
+ *   coef   [n_drones][n_seg][4][ncoef]  out, ascending powers
+ *   dur    [n_drones][n_seg]            out, T_i = t[i+1]-t[i]  (time_points, :59-61)
+ *   status [n_drones]                   out, msnap_status
+ * Drones with status != 0 get NaN coefficients.
+ */
+int msnap_solve_batch(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
+                      const double *t, int shared_times, double *coef, double *dur,
+                      int32_t *status);
+int msnap_solve_batch_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
+                             const double *t, int shared_times, double *coef,
+                             double *dur, int32_t *status);
+
+/* ---- a7: the float32 [T | x | y | z | yaw] matrix of path_to_pol -----------------
+ * replaces scripts/drones_pols_generator.py:63-77.
+ *   out [n_drones][n_seg][1 + 4*ncoef] float32
+ */
+int msnap_pack_pol_matrix(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                          const double *dur, float *out);
+int msnap_pack_pol_matrix_device(msnap_ctx *ctx, int n_drones, int n_seg,
+                                 const double *coef, const double *dur, float *out);
+
+/* ---- a8: transform(path) of the formation node, K offsets ------------------------
+ * replaces scripts/drones_traj_generator.py:56-89 (K = 2 hard-coded there).
+ *   rb_pose [n_poses][7]   x y z qx qy qz qw of the rigid body
+ *   offsets [n_offsets][3] body-frame drone positions (identity orientation)
+ *   out     [n_offsets][n_poses][7]   p' = R(q) p_k + t,  q' = q (x) (0,0,0,1)
+ */
+int msnap_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets,
+                              const double *rb_pose, const double *offsets, double *out);
+int msnap_formation_transform_device(msnap_ctx *ctx, int n_poses, int n_offsets,
+                                     const double *rb_pose, const double *offsets,
+                                     double *out);
+
+/* ---- a5: PiecewisePolynomial.eval on a uniform grid -------------------------------
+ * replaces src/optimizations/uav_trajectory.py:154-169 (strict '<' lookup, the
+ * last piece extrapolates) sampled as np.arange(0, .., dt) (scripts/path_vis.py:28,
+ * src/trajectory_visualising/visualization.py:53).
+ *   pos [n_drones][n_samples][n_axes]  (n_axes = 3: x,y,z; 4: + yaw), sample s at t = s*dt
+ */
+int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                 const double *dur, double dt, int n_samples, int n_axes, double *pos);
+int msnap_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                        const double *dur, double dt, int n_samples, int n_axes,
+                        double *pos);
+
+/* ---- drone-vs-drone formation pass (new capability; no reference) -------
+ * rows: the n_rows drones this caller owns (a shard), starting at global index
+ * row_offset; cols: all n_cols drones (after the all-gather).  Spheres of `radius`.
+ *   pos_rows [n_rows][n_samples][3], pos_cols [n_cols][n_samples][3]
+ *   min_dist [n_rows]  min over other drones j != global row and samples of |p_i-p_j|
+ *   partner  [n_rows]  lowest global j attaining it (-1 if none)
+ *   hit      [n_rows]  min_dist < 2*radius
+ */
+int msnap_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
+                            int n_samples, const double *pos_rows, const double *pos_cols,
+                            double radius, double *min_dist, int32_t *partner,
+                            int32_t *hit);
+int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
+                                   int n_samples, const double *pos_rows,
+                                   const double *pos_cols, double radius,
+                                   double *min_dist, int32_t *partner, int32_t *hit);
+
+/* ---- drone-vs-mesh sweep against resources/stl obstacles (new capability) ----------
+ *   tris [n_tris][3][3] fp64 vertices (binary STL float32 widened by the caller)
+ *   min_dist [n_drones] min over samples and triangles of the point-triangle distance
+ *   hit      [n_drones] min_dist < radius
+ */
+int msnap_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos,
+                     int n_tris, const double *tris, double radius, double *min_dist,
+                     int32_t *hit);
+int msnap_mesh_sweep_device(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos,
+                            int n_tris, const double *tris, double radius,
+                            double *min_dist, int32_t *hit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSNAP_H */
