@@ -10,7 +10,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmsnap.so")
+# MSNAP_LIB_PATH: experiment builds only (e.g. a timing variant of the same ABI)
+LIB_PATH = os.environ.get("MSNAP_LIB_PATH") or os.path.join(_HERE, "csrc", "libmsnap.so")
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -28,6 +29,7 @@ SIGNATURES = {
     "msnap_create": (_I, [c_void_pp, _I, _I, _I]),
     "msnap_destroy": (None, [_VP]),
     "msnap_set_stream": (_I, [_VP, _VP]),
+    "msnap_use_own_stream": (_I, [_VP]),
     "msnap_get_stream": (_VP, [_VP]),
     "msnap_sync": (_I, [_VP]),
     "msnap_timer_start": (_I, [_VP]),

@@ -76,8 +76,13 @@ class Context:
 
     # ---- stream / timing ------------------------------------------------------
     def set_stream(self, hip_stream: int | None):
+        """Launch on an external hipStream_t (0 / None = the HIP null stream)."""
         with self._lock:
             self._ck(self._lib.msnap_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def use_own_stream(self):
+        with self._lock:
+            self._ck(self._lib.msnap_use_own_stream(self._h))
 
     def stream(self) -> int:
         return int(self._lib.msnap_get_stream(self._h) or 0)

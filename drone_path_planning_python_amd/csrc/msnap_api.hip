@@ -108,7 +108,13 @@ void msnap_destroy(msnap_ctx *ctx) {
 
 int msnap_set_stream(msnap_ctx *ctx, void *hip_stream) {
   if (!ctx) return MSNAP_EINVAL;
-  ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return MSNAP_OK;
+}
+
+int msnap_use_own_stream(msnap_ctx *ctx) {
+  if (!ctx) return MSNAP_EINVAL;
+  ctx->stream = ctx->own_stream;
   return MSNAP_OK;
 }
 

@@ -16,14 +16,16 @@ constexpr int kAxes = 4;                // x, y, z, yaw: one lane each
 constexpr int kDronesPerWave = 16;      // 16 drones x 4 axis-lanes = one wavefront
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
-// number of scratch doubles one 16-drone tile needs in the K1 solve
-// (waypoint stash, T, 1/T, G_i blocks, z_i vectors) -- see msnap_solve.hip
+// doubles one 16-drone tile of the K1 solve keeps between its forward and backward
+// sweep (1/T, G_i blocks, z_i vectors) -- LDS, or a global slab for very long paths
 inline size_t solve_scratch_words(int khalf, int n_seg) {
   const size_t nu = (size_t)khalf - 1;
   const size_t M = (size_t)n_seg;
   const size_t knots = M > 0 ? M - 1 : 0;
-  return 64 * (M + 1) + 16 * M * 2 + 16 * nu * nu * knots + 64 * nu * knots;
+  return 16 * M + 16 * nu * nu * knots + 64 * nu * knots;
 }
+// doubles of the LDS input stage (raw copy of the tile's waypoints and times)
+inline size_t solve_input_words(int n_seg) { return (size_t)16 * (n_seg + 1) * 5; }
 
 // growable device buffer
 struct DevBuf {

@@ -21,16 +21,18 @@
 // Mapping: lane = 4*dl + axis; a wavefront carries 16 drones.  The matrix part
 // (S_i, G_i) depends on the time grid only and is recomputed by the 4 axis
 // lanes of a drone (no cross-lane traffic, no divergence: every lane runs the
-// same M-step recurrence).  Per-knot G_i (once per drone) and z_i (per lane)
-// live in LDS; when n_seg is too large for 160 KiB the same code runs on a
-// global-memory scratch slab (GS = true).
+// same M-step recurrence).  The tile's inputs are staged in LDS by one
+// coalesced sweep.  Three variants share the arithmetic:
+//   solve_kernel_reg<K, MAXM>  n_seg <= MAXM: z_i in registers (loops unrolled),
+//                              G_i in LDS -> 8 waves / CU              (fast path)
+//   solve_kernel<K, false>     any n_seg that fits 160 KiB: G_i and z_i in LDS
+//   solve_kernel<K, true>      longer paths: G_i, z_i on a global scratch slab
 #include "msnap_consts.h"
 #include "msnap_internal.h"
 
 namespace msnap {
 
-template <int NU>
-__device__ __forceinline__ constexpr int sidx(int r, int c) {  // r >= c
+__device__ __forceinline__ constexpr int sidx(int r, int c) {  // symmetric lower, r >= c
   return r * (r + 1) / 2 + c;
 }
 
@@ -51,84 +53,44 @@ __device__ __forceinline__ double rcp64(double v) {
 
 __device__ __forceinline__ bool finite64(double v) { return __builtin_isfinite(v); }
 
-template <int K, bool GS>
-__global__ void __launch_bounds__(kWave)
-solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
-             int N, int M, double *__restrict__ coef, double *__restrict__ dur,
-             int32_t *__restrict__ status, double *__restrict__ gscratch, int ntiles) {
-  constexpr int NU = K - 1;           // unknown derivatives per interior knot
-  constexpr int NC = 2 * K;           // coefficients per segment
-  constexpr int KK = 2 * K - 1;       // polynomial order
-  constexpr int NS = NU * (NU + 1) / 2;
-  constexpr int PM = 2 * K - 2;       // highest power of 1/T needed in the sweep
+// ------------------------------------------------------------------------------------
+// the forward recurrence carried from knot to knot
+// ------------------------------------------------------------------------------------
+template <int K>
+struct Sweep {
+  static constexpr int NU = K - 1;            // unknown derivatives per interior knot
+  static constexpr int NC = 2 * K;            // coefficients per segment
+  static constexpr int KK = 2 * K - 1;        // polynomial order
+  static constexpr int NS = NU * (NU + 1) / 2;
+  static constexpr int PM = 2 * K - 2;        // highest power of 1/T in the sweep
   using C = HermiteConsts<K>;
 
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double E[NS], re[NU];                       // end side of the previous segment
+  double Op[NU][NU], Gp[NU][NU], zp[NU];      // O_{i-1}, G_{i-1}, z_{i-1}
+  bool singular;
 
-  const int lane = threadIdx.x;
-  const int dl = lane >> 2;
-  const int a = lane & 3;
-  const int knots = M - 1;
-
-  // scratch carve (doubles): W[(M+1)][64] | T[M][16] | X[M][16] | G[knots][NU*NU][16] | Z[knots][NU][64]
-  double *scr;
-  if constexpr (GS) {
-    scr = gscratch + (size_t)blockIdx.x *
-                         (size_t)(64 * (M + 1) + 32 * M + 16 * NU * NU * knots + 64 * NU * knots);
-  } else {
-    scr = lds;
-  }
-  double *sW = scr;
-  double *sT = sW + 64 * (M + 1);
-  double *sX = sT + 16 * M;
-  double *sG = sX + 16 * M;
-  double *sZ = sG + 16 * NU * NU * knots;
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int d_raw = tile * kDronesPerWave + dl;
-    const bool live = d_raw < N;
-    const int d = live ? d_raw : N - 1;
-    const double *wrow = wp + (size_t)d * (size_t)(M + 1) * 4 + a;
-    const double *trow = shared_times ? tt : tt + (size_t)d * (size_t)(M + 1);
-    double *drow = dur + (size_t)d * M;
-
-    // ---------------- segment 0: only its end side feeds knot 1 ----------------
-    const double t0 = trow[0];
-    double tcur = trow[1];
-    double wprev = wrow[0];
-    double wcur = wrow[4];
-    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(wprev) && finite64(wcur));
-    double T = tcur - t0;
-    // Appendix-A quirk of the reference (calculatingTrajectories.py:59,65-73):
-    // the start rows are evaluated at local time t[0], the end of segment 0 at
-    // t[1]-t[0]; segment 0 is therefore a Hermite piece of length T - t0 in the
-    // shifted variable s - t0 (identity when t[0] == 0).
-    double Teff = T - t0;
-    bool badtime = !(T > 0.0) || !(Teff > 0.0) || (t0 < 0.0);
-    bool singular = false;
-    if (live && a == 0) drow[0] = T;
-    double x = rcp64(Teff);
-    sW[0 * 64 + lane] = wprev;
-    sW[1 * 64 + lane] = wcur;
-    sT[0 * 16 + dl] = Teff;
-    sX[0 * 16 + dl] = x;
-
-    double xp[PM + 1];
+  __device__ __forceinline__ static void powers(double x, double (&xp)[PM + 1]) {
     xp[0] = 1.0;
     xp[1] = x;
 #pragma unroll
     for (int p = 2; p <= PM; ++p) xp[p] = xp[p - 1] * x;
+  }
 
-    double dw = wcur - wprev;
-    double E[NS], re[NU];
+  __device__ __forceinline__ void end_side(const double (&xp)[PM + 1], double dw) {
 #pragma unroll
     for (int n = 1; n <= NU; ++n) {
 #pragma unroll
-      for (int m = 1; m <= n; ++m) E[sidx<NU>(n - 1, m - 1)] = C::HEE[n][m] * xp[KK - n - m];
+      for (int m = 1; m <= n; ++m) E[sidx(n - 1, m - 1)] = C::HEE[n][m] * xp[KK - n - m];
       re[n - 1] = (C::HEE[n][0] * xp[KK - n]) * dw;
     }
+  }
 
-    double Op[NU][NU], Gp[NU][NU], zp[NU];
+  // segment 0 (x = 1/T_0, dw = w_1 - w_0): only its end side feeds knot 1
+  __device__ __forceinline__ void init(double x, double dw) {
+    double xp[PM + 1];
+    powers(x, xp);
+    end_side(xp, dw);
+    singular = false;
 #pragma unroll
     for (int r = 0; r < NU; ++r) {
       zp[r] = 0.0;
@@ -138,99 +100,357 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
         Gp[r][c] = 0.0;
       }
     }
+  }
 
-    // ---------------- forward block LDL^T sweep over interior knots ----------------
-    for (int i = 1; i < M; ++i) {
-      const double tnext = trow[i + 1];
-      const double wnext = wrow[(size_t)(i + 1) * 4];
-      nonfinite = nonfinite || !finite64(tnext) || !finite64(wnext);
-      T = tnext - tcur;
-      badtime = badtime || !(T > 0.0);
-      if (live && a == 0) drow[i] = T;
-      x = rcp64(T);
-      sW[(i + 1) * 64 + lane] = wnext;
-      sT[i * 16 + dl] = T;
-      sX[i * 16 + dl] = x;
-      xp[1] = x;
-#pragma unroll
-      for (int p = 2; p <= PM; ++p) xp[p] = xp[p - 1] * x;
-      dw = wnext - wcur;
+  // knot i with segment i (x = 1/T_i, dw = w_{i+1} - w_i) on its right:
+  // S_i = D_i - O_{i-1}^T G_{i-1}, LDL^T, G_i = S_i^-1 O_i, z_i = S_i^-1 y_i
+  __device__ __forceinline__ void step(double x, double dw, double (&G)[NU][NU], double (&z)[NU]) {
+    double xp[PM + 1];
+    powers(x, xp);
 
-      // S_i = D_i - O_{i-1}^T G_{i-1}   (symmetric, lower triangle)
-      double S[NS], y[NU];
+    double S[NS], y[NU];
 #pragma unroll
-      for (int n = 1; n <= NU; ++n) {
+    for (int n = 1; n <= NU; ++n) {
 #pragma unroll
-        for (int m = 1; m <= n; ++m) {
-          double v = __builtin_fma(C::HSS[n][m], xp[KK - n - m], E[sidx<NU>(n - 1, m - 1)]);
+      for (int m = 1; m <= n; ++m) {
+        double v = __builtin_fma(C::HSS[n][m], xp[KK - n - m], E[sidx(n - 1, m - 1)]);
 #pragma unroll
-          for (int q = 0; q < NU; ++q) v = __builtin_fma(-Op[q][n - 1], Gp[q][m - 1], v);
-          S[sidx<NU>(n - 1, m - 1)] = v;
-        }
-        double rv = -__builtin_fma(C::HSE[n][0] * xp[KK - n], dw, re[n - 1]);
-#pragma unroll
-        for (int q = 0; q < NU; ++q) rv = __builtin_fma(-Op[q][n - 1], zp[q], rv);
-        y[n - 1] = rv;
+        for (int q = 0; q < NU; ++q) v = __builtin_fma(-Op[q][n - 1], Gp[q][m - 1], v);
+        S[sidx(n - 1, m - 1)] = v;
       }
+      double rv = -__builtin_fma(C::HSE[n][0] * xp[KK - n], dw, re[n - 1]);
+#pragma unroll
+      for (int q = 0; q < NU; ++q) rv = __builtin_fma(-Op[q][n - 1], zp[q], rv);
+      y[n - 1] = rv;
+    }
 
-      // LDL^T of S: L unit lower (stored in S's strict lower part), dinv
-      double dinv[NU];
+    // LDL^T of S; S's strict lower part holds w_rp = L_rp d_p until scaled
+    double dinv[NU];
 #pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        double dj = S[sidx<NU>(j, j)];
+    for (int j = 0; j < NU; ++j) {
+      double dj = S[sidx(j, j)];
 #pragma unroll
-        for (int p = 0; p < j; ++p) {
-          // S(j,p) holds w_jp = L_jp * d_p until scaled below
-          dj = __builtin_fma(-S[sidx<NU>(j, p)] * dinv[p], S[sidx<NU>(j, p)], dj);
-        }
-        singular = singular || !(dj > 0.0) || !finite64(dj);
-        dinv[j] = rcp64(dj);
+      for (int p = 0; p < j; ++p) dj = __builtin_fma(-S[sidx(j, p)] * dinv[p], S[sidx(j, p)], dj);
+      singular = singular || !(dj > 0.0) || !finite64(dj);
+      dinv[j] = rcp64(dj);
 #pragma unroll
-        for (int r = j + 1; r < NU; ++r) {
-          double v = S[sidx<NU>(r, j)];
+      for (int r = j + 1; r < NU; ++r) {
+        double v = S[sidx(r, j)];
 #pragma unroll
-          for (int p = 0; p < j; ++p) v = __builtin_fma(-S[sidx<NU>(r, p)] * dinv[p], S[sidx<NU>(j, p)], v);
-          S[sidx<NU>(r, j)] = v;  // w_rj = L_rj d_j
-        }
+        for (int p = 0; p < j; ++p) v = __builtin_fma(-S[sidx(r, p)] * dinv[p], S[sidx(j, p)], v);
+        S[sidx(r, j)] = v;
       }
-      // convert w -> L
+    }
+#pragma unroll
+    for (int r = 1; r < NU; ++r)
+#pragma unroll
+      for (int p = 0; p < r; ++p) S[sidx(r, p)] *= dinv[p];
+
+    double O[NU][NU];
+#pragma unroll
+    for (int n = 1; n <= NU; ++n)
+#pragma unroll
+      for (int m = 1; m <= NU; ++m) O[n - 1][m - 1] = C::HSE[n][m] * xp[KK - n - m];
+
+    // NU + 1 solves with the factor: columns of O_i, then y
+#pragma unroll
+    for (int c = 0; c <= NU; ++c) {
+      double v[NU];
+#pragma unroll
+      for (int r = 0; r < NU; ++r) v[r] = (c < NU) ? O[r][c < NU ? c : 0] : y[r];
 #pragma unroll
       for (int r = 1; r < NU; ++r)
 #pragma unroll
-        for (int p = 0; p < r; ++p) S[sidx<NU>(r, p)] *= dinv[p];
-
-      // O_i and the NU+1 solves  G_i = S^-1 O_i ,  z_i = S^-1 y
-      double O[NU][NU], G[NU][NU], z[NU];
+        for (int p = 0; p < r; ++p) v[r] = __builtin_fma(-S[sidx(r, p)], v[p], v[r]);
 #pragma unroll
-      for (int n = 1; n <= NU; ++n)
+      for (int r = 0; r < NU; ++r) v[r] *= dinv[r];
 #pragma unroll
-        for (int m = 1; m <= NU; ++m) O[n - 1][m - 1] = C::HSE[n][m] * xp[KK - n - m];
-
+      for (int r = NU - 2; r >= 0; --r)
 #pragma unroll
-      for (int c = 0; c <= NU; ++c) {
-        double v[NU];
+        for (int p = r + 1; p < NU; ++p) v[r] = __builtin_fma(-S[sidx(p, r)], v[p], v[r]);
 #pragma unroll
-        for (int r = 0; r < NU; ++r) v[r] = (c < NU) ? O[r][c < NU ? c : 0] : y[r];
-        // forward  L v' = v
-#pragma unroll
-        for (int r = 1; r < NU; ++r)
-#pragma unroll
-          for (int p = 0; p < r; ++p) v[r] = __builtin_fma(-S[sidx<NU>(r, p)], v[p], v[r]);
-#pragma unroll
-        for (int r = 0; r < NU; ++r) v[r] *= dinv[r];
-        // backward L^T v'' = v'
-#pragma unroll
-        for (int r = NU - 2; r >= 0; --r)
-#pragma unroll
-          for (int p = r + 1; p < NU; ++p) v[r] = __builtin_fma(-S[sidx<NU>(p, r)], v[p], v[r]);
-#pragma unroll
-        for (int r = 0; r < NU; ++r) {
-          if (c < NU) G[r][c < NU ? c : 0] = v[r];
-          else z[r] = v[r];
-        }
+      for (int r = 0; r < NU; ++r) {
+        if (c < NU) G[r][c < NU ? c : 0] = v[r];
+        else z[r] = v[r];
       }
+    }
 
-      // stash for the backward sweep
+    end_side(xp, dw);   // carry: end side of segment i feeds knot i+1
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      zp[r] = z[r];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        Op[r][c] = O[r][c];
+        Gp[r][c] = G[r][c];
+      }
+    }
+  }
+};
+
+// monomial coefficients of one segment from its endpoint states
+// (u = d_i[1..k-1], un = d_{i+1}[1..k-1], Ti, xi = 1/Ti, dwi = w_{i+1} - w_i)
+template <int K>
+__device__ __forceinline__ void recover_segment(double wi, double dwi, double Ti, double xi,
+                                                const double (&u)[K - 1], const double (&un)[K - 1],
+                                                double (&c)[2 * K]) {
+  using C = HermiteConsts<K>;
+  constexpr int NC = 2 * K;
+  double tp[K];
+  tp[0] = 1.0;
+#pragma unroll
+  for (int n = 1; n < K; ++n) tp[n] = tp[n - 1] * Ti;
+  double xq[NC];
+  xq[0] = 1.0;
+#pragma unroll
+  for (int m = 1; m < NC; ++m) xq[m] = xq[m - 1] * xi;
+  c[0] = wi;
+#pragma unroll
+  for (int n = 1; n < K; ++n) c[n] = u[n - 1] * C::INVFACT[n];
+  double es[K], ee[K];
+#pragma unroll
+  for (int n = 1; n < K; ++n) {
+    es[n] = tp[n] * u[n - 1];
+    ee[n] = tp[n] * un[n - 1];
+  }
+#pragma unroll
+  for (int m = 0; m < K; ++m) {
+    double acc = C::CE[m][0] * dwi;
+#pragma unroll
+    for (int n = 1; n < K; ++n) {
+      acc = __builtin_fma(C::CS[m][n], es[n], acc);
+      acc = __builtin_fma(C::CE[m][n], ee[n], acc);
+    }
+    c[K + m] = acc * xq[K + m];
+  }
+}
+
+// p(s) = q(s - t0): the reference evaluates the start rows of segment 0 at local
+// time t[0] (calculatingTrajectories.py:59,65-73), so that piece is a Hermite
+// segment of length T_0 - t0 in the shifted variable (identity for t[0] == 0).
+template <int NC>
+__device__ __forceinline__ void taylor_shift(double (&c)[NC], double h) {
+#pragma unroll
+  for (int j = 0; j < NC - 1; ++j)
+#pragma unroll
+    for (int q = NC - 2; q >= j; --q) c[q] = __builtin_fma(h, c[q + 1], c[q]);
+}
+
+template <int NC>
+__device__ __forceinline__ void store_segment(double *__restrict__ o, double (&c)[NC], bool bad, bool live) {
+  if (bad) {
+#pragma unroll
+    for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
+  }
+#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
+  live = live && (c[0] == 12345.678);
+#endif
+  if (live) {
+#pragma unroll
+    for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
+  }
+}
+
+// Full-line output stores.  A lane owns the NC coefficients of one (drone, axis):
+// stored directly, a wave instruction would scatter 64 x 16 B over 64 different
+// 64-byte segments.  Instead the segment's 64 x NC doubles take a round trip
+// through an LDS image [NC/2 rows][68 slots of 16 B] (row pitch 68 keeps
+// ds_read_b128 conflict-free for NC = 8) and leave as 16-B-per-lane stores that
+// are contiguous over each drone's 4*NC*8-byte block (256 B = two full lines).
+// LDS is in-order within a wave; the wavefront-scope fences only pin the
+// compiler's ordering (no vmcnt wait: output stores stay in flight).
+constexpr int kTrPitch = 68;
+template <int NC>
+__device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__restrict__ seg_base,
+                                                        size_t drone_stride, int nvalid, int lane,
+                                                        double (&c)[NC], bool bad) {
+  constexpr int NJ = NC / 2;
+  if (bad) {
+#pragma unroll
+    for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sTr[j * kTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#pragma unroll
+  for (int q = 0; q < NJ; ++q) {
+    const int s = q * kWave + lane;          // flat 16-byte slot of the tile-segment
+    const int drone = s / (4 * NJ);
+    const int within = s - drone * (4 * NJ);
+    const int a2 = within / NJ;
+    const int j2 = within - a2 * NJ;
+    const double2 v = sTr[j2 * kTrPitch + drone * 4 + a2];
+    bool ok = drone < nvalid;
+#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
+    ok = ok && (v.x == 12345.678);
+#endif
+    if (ok) *reinterpret_cast<double2 *>(seg_base + (size_t)drone * drone_stride + within * 2) = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
+__device__ __forceinline__ void store_durations(const double *sTraw, int shared_times, int tpitch, int M,
+                                                int nvalid, int lane, double *__restrict__ dur_tile) {
+  const int cnt = nvalid * M;
+  for (int e = lane; e < cnt; e += kWave) {
+    const int dl = e / M;
+    const int i = e - dl * M;
+    const double *lt = sTraw + (shared_times ? 0 : dl * tpitch);
+    dur_tile[e] = lt[i + 1] - lt[i];
+  }
+}
+
+__device__ __forceinline__ int drone_status(bool nonfinite, bool badtime, bool singular) {
+  int flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (singular ? 1 : 0);
+  flags |= __shfl_xor(flags, 1);   // combine the 4 axis lanes of the drone
+  flags |= __shfl_xor(flags, 2);
+  return (flags & 4) ? MSNAP_ST_NONFINITE : (flags & 2) ? MSNAP_ST_TIMES : (flags & 1) ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
+}
+
+// one coalesced sweep of the tile's waypoints and times into LDS, all loads in flight
+__device__ __forceinline__ void stage_inputs(const double *__restrict__ wp, const double *__restrict__ tt,
+                                             int shared_times, int tile, int nvalid, int wpitch, int tpitch,
+                                             double *sWraw, double *sTraw, int lane) {
+  const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kDronesPerWave * wpitch);
+  double2 *wdst = reinterpret_cast<double2 *>(sWraw);
+  const int wcnt = nvalid * wpitch / 2;   // wpitch is a multiple of 4
+  const double *tsrc = shared_times ? tt : tt + (size_t)tile * kDronesPerWave * tpitch;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+  constexpr int UW = 8, UT = 4;           // the first round covers n_seg <= 14
+  for (int e0 = 0, f0 = 0; e0 < wcnt || f0 < tcnt; e0 += UW * kWave, f0 += UT * kWave) {
+    double2 vw[UW];
+    double vt[UT];
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      const int e = e0 + u * kWave + lane;
+      vw[u] = wsrc[e < wcnt ? e : wcnt - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int f = f0 + u * kWave + lane;
+      vt[u] = tsrc[f < tcnt ? f : tcnt - 1];
+    }
+    // pin: keeps the compiler from sinking each load next to its guarded store
+#pragma unroll
+    for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(vw[u].x), "+v"(vw[u].y));
+#pragma unroll
+    for (int u = 0; u < UT; ++u) asm volatile("" : "+v"(vt[u]));
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      const int e = e0 + u * kWave + lane;
+      if (e < wcnt) wdst[e] = vw[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int f = f0 + u * kWave + lane;
+      if (f < tcnt) sTraw[f] = vt[u];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// generic variant: rolled loops, G_i / z_i stashed in LDS (GS = false) or on a
+// global slab (GS = true)
+// ------------------------------------------------------------------------------------
+template <int K, bool GS>
+__global__ void __launch_bounds__(kWave)
+solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+             int N, int M, double *__restrict__ coef, double *__restrict__ dur,
+             int32_t *__restrict__ status, double *__restrict__ gscratch, int ntiles) {
+  using SW = Sweep<K>;
+  constexpr int NU = SW::NU, NC = SW::NC;
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int lane = threadIdx.x;
+  const int dl = lane >> 2;
+  const int a = lane & 3;
+  const int knots = M - 1;
+  const int wpitch = (M + 1) * 4;
+  const int tpitch = M + 1;
+
+  // LDS: output transpose image Tr[NC/2][68] (16-B slots) | then, LDS variant only,
+  //      inputs Wraw[16][(M+1)*4] | Traw[16][M+1]
+  // stash (LDS or global slab): X[M][16] | G[knots][NU*NU][16] | Z[knots][NU][64]
+  double2 *sTr = reinterpret_cast<double2 *>(lds);
+  double *sWraw = lds + (NC / 2) * kTrPitch * 2;
+  double *sTraw = sWraw + 16 * wpitch;
+  double *scr;
+  if constexpr (GS) {
+    scr = gscratch + (size_t)blockIdx.x * (size_t)(16 * M + 16 * NU * NU * knots + 64 * NU * knots);
+  } else {
+    scr = sTraw + 16 * tpitch;
+  }
+  double *sX = scr;
+  double *sG = sX + 16 * M;
+  double *sZ = sG + 16 * NU * NU * knots;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int d_raw = tile * kDronesPerWave + dl;
+    const bool live = d_raw < N;
+    const int d = live ? d_raw : N - 1;
+    const double *wrow = wp + (size_t)d * (size_t)wpitch + a;
+    const double *trow = shared_times ? tt : tt + (size_t)d * (size_t)tpitch;
+    double *drow = dur + (size_t)d * M;
+
+    const int left = N - tile * kDronesPerWave;
+    const int nvalid = left < kDronesPerWave ? left : kDronesPerWave;
+    if constexpr (!GS) {
+      if (tile != (int)blockIdx.x) __syncthreads();  // LDS is reused by this block's next tile
+      stage_inputs(wp, tt, shared_times, tile, nvalid, wpitch, tpitch, sWraw, sTraw, lane);
+      __syncthreads();
+      store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
+    }
+    // lanes past the end of the batch replay the last valid drone (stores are masked)
+    const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
+    const double *lw = sWraw + dloc * wpitch + a;
+    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
+    auto Wv = [&](int i) -> double { if constexpr (GS) return wrow[(size_t)i * 4]; else return lw[i * 4]; };
+    auto Tv = [&](int i) -> double { if constexpr (GS) return trow[i]; else return lt[i]; };
+
+    // ---------------- segment 0 ----------------
+    const double t0 = Tv(0);
+    double tcur = Tv(1);
+    const double w0 = Wv(0);
+    double wcur = Wv(1);
+    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(w0) && finite64(wcur));
+    double T = tcur - t0;
+    const double Teff = T - t0;   // Appendix-A quirk, see taylor_shift()
+    bool badtime = !(T > 0.0) || !(Teff > 0.0) || (t0 < 0.0);
+    if constexpr (GS) {
+      if (live && a == 0) drow[0] = T;
+    }
+    double x = rcp64(Teff);
+    sX[0 * 16 + dl] = x;
+    SW sw;
+    sw.init(x, wcur - w0);
+
+    // ---------------- forward block LDL^T sweep over interior knots ----------------
+    // operands of knot i+1 are fetched one iteration ahead (LDS latency off the chain)
+    double tpre = Tv(M >= 2 ? 2 : M);
+    double wpre = Wv(M >= 2 ? 2 : M);
+    for (int i = 1; i < M; ++i) {
+      const double tnext = tpre;
+      const double wnext = wpre;
+      {
+        const int ip = (i + 2 <= M) ? i + 2 : M;
+        tpre = Tv(ip);
+        wpre = Wv(ip);
+      }
+      nonfinite = nonfinite || !finite64(tnext) || !finite64(wnext);
+      T = tnext - tcur;
+      badtime = badtime || !(T > 0.0);
+      if constexpr (GS) {
+        if (live && a == 0) drow[i] = T;
+      }
+      x = rcp64(T);
+      sX[i * 16 + dl] = x;
+      double G[NU][NU], z[NU];
+      sw.step(x, wnext - wcur, G, z);
       double *g = sG + (size_t)(i - 1) * (NU * NU * 16) + dl;
       double *zz = sZ + (size_t)(i - 1) * (NU * 64) + lane;
 #pragma unroll
@@ -239,134 +459,244 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
         for (int c = 0; c < NU; ++c) g[(r * NU + c) * 16] = G[r][c];
         zz[r * 64] = z[r];
       }
-
-      // carry: end side of segment i feeds knot i+1
-#pragma unroll
-      for (int n = 1; n <= NU; ++n) {
-#pragma unroll
-        for (int m = 1; m <= n; ++m) E[sidx<NU>(n - 1, m - 1)] = C::HEE[n][m] * xp[KK - n - m];
-        re[n - 1] = (C::HEE[n][0] * xp[KK - n]) * dw;
-      }
-#pragma unroll
-      for (int r = 0; r < NU; ++r) {
-        zp[r] = z[r];
-#pragma unroll
-        for (int c = 0; c < NU; ++c) {
-          Op[r][c] = O[r][c];
-          Gp[r][c] = G[r][c];
-        }
-      }
       tcur = tnext;
       wcur = wnext;
     }
 
-    // ---------------- per-drone status (combine the 4 axis lanes) ----------------
-    int flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (singular ? 1 : 0);
-    flags |= __shfl_xor(flags, 1);
-    flags |= __shfl_xor(flags, 2);
-    const int st = (flags & 4) ? MSNAP_ST_NONFINITE
-                   : (flags & 2) ? MSNAP_ST_TIMES
-                   : (flags & 1) ? MSNAP_ST_SINGULAR
-                                 : MSNAP_ST_OK;
+    const int st = drone_status(nonfinite, badtime, sw.singular);
     if (live && a == 0) status[d] = st;
     const bool bad = st != 0;
 
-    if constexpr (!GS) __syncthreads();  // one-wave workgroup: orders the LDS stash
-
     // ---------------- backward sweep + coefficient recovery ----------------
-    double un[NU];
+    // operands of segment i-1 are fetched while segment i is being recovered
+    double un[NU], zq[NU], gq[NU][NU];
 #pragma unroll
     for (int r = 0; r < NU; ++r) un[r] = 0.0;
-    double wn = wcur;  // w_M
+    double wn = wcur;   // w_M
+    double thi = tcur;  // t_M
+    double wq = Wv(M - 1), tq = Tv(M - 1), xq1 = sX[(M - 1) * 16 + dl];
+    {
+      const int kq = (M >= 2) ? M - 2 : 0;  // stash slot of knot M-1
+      const double *zz = sZ + (size_t)kq * (NU * 64) + lane;
+      const double *g = sG + (size_t)kq * (NU * NU * 16) + dl;
+#pragma unroll
+      for (int r = 0; r < NU; ++r) {
+        zq[r] = (M >= 2) ? zz[r * 64] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NU; ++c) gq[r][c] = (M >= 2) ? g[(r * NU + c) * 16] : 0.0;
+      }
+    }
     for (int i = M - 1; i >= 0; --i) {
       double u[NU];
-      if (i >= 1) {
-        const double *zz = sZ + (size_t)(i - 1) * (NU * 64) + lane;
+      const double wi = wq;
+      const double tlo = tq;
+      const double xi = xq1;
 #pragma unroll
-        for (int r = 0; r < NU; ++r) u[r] = zz[r * 64];
+      for (int r = 0; r < NU; ++r) {
+        double v = zq[r];
         if (i < M - 1) {
-          const double *g = sG + (size_t)(i - 1) * (NU * NU * 16) + dl;
 #pragma unroll
-          for (int r = 0; r < NU; ++r)
-#pragma unroll
-            for (int c = 0; c < NU; ++c) u[r] = __builtin_fma(-g[(r * NU + c) * 16], un[c], u[r]);
+          for (int c = 0; c < NU; ++c) v = __builtin_fma(-gq[r][c], un[c], v);
         }
-      } else {
-#pragma unroll
-        for (int r = 0; r < NU; ++r) u[r] = 0.0;
+        u[r] = (i >= 1) ? v : 0.0;
       }
-      const double wi = sW[i * 64 + lane];
-      const double Ti = sT[i * 16 + dl];
-      const double xi = sX[i * 16 + dl];
-      const double dwi = wn - wi;
-
-      double tp[K];        // Ti^n, n < K
-      tp[0] = 1.0;
+      if (i >= 1) {
+        wq = Wv(i - 1);
+        tq = Tv(i - 1);
+        xq1 = sX[(i - 1) * 16 + dl];
+        if (i >= 2) {
+          const double *zz = sZ + (size_t)(i - 2) * (NU * 64) + lane;
+          const double *g = sG + (size_t)(i - 2) * (NU * NU * 16) + dl;
 #pragma unroll
-      for (int n = 1; n < K; ++n) tp[n] = tp[n - 1] * Ti;
-      double xq[NC];       // xi^m
-      xq[0] = 1.0;
+          for (int r = 0; r < NU; ++r) {
+            zq[r] = zz[r * 64];
 #pragma unroll
-      for (int m = 1; m < NC; ++m) xq[m] = xq[m - 1] * xi;
-
+            for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
+          }
+        }
+      }
+      const double Ti = (i == 0) ? (thi - tlo) - tlo : thi - tlo;
+      thi = tlo;
       double c[NC];
-      c[0] = wi;
-#pragma unroll
-      for (int n = 1; n < K; ++n) c[n] = u[n - 1] * C::INVFACT[n];
-      double es[K], ee[K];
-#pragma unroll
-      for (int n = 1; n < K; ++n) {
-        es[n] = tp[n] * u[n - 1];
-        ee[n] = tp[n] * un[n - 1];
-      }
-#pragma unroll
-      for (int m = 0; m < K; ++m) {
-        double acc = C::CE[m][0] * dwi;
-#pragma unroll
-        for (int n = 1; n < K; ++n) {
-          acc = __builtin_fma(C::CS[m][n], es[n], acc);
-          acc = __builtin_fma(C::CE[m][n], ee[n], acc);
-        }
-        c[K + m] = acc * xq[K + m];
-      }
-
-      if (i == 0 && t0 != 0.0) {
-        // p(s) = q(s - t0): Taylor shift of segment 0 (reference quirk, see above)
-        const double h = -t0;
-#pragma unroll
-        for (int j = 0; j < NC - 1; ++j)
-#pragma unroll
-          for (int q = NC - 2; q >= j; --q) c[q] = __builtin_fma(h, c[q + 1], c[q]);
-      }
-
-      if (bad) {
-#pragma unroll
-        for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
-      }
-      if (live) {
-        double *o = coef + (((size_t)d * M + i) * 4 + a) * NC;
-#pragma unroll
-        for (int m = 0; m < NC; m += 2) {
-          double2 v2 = make_double2(c[m], c[m + 1]);
-          *reinterpret_cast<double2 *>(o + m) = v2;
-        }
-      }
+      recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
+      if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+      store_segment_coalesced<NC>(sTr, coef + ((size_t)tile * kDronesPerWave * M + i) * (4 * NC),
+                                  (size_t)M * 4 * NC, nvalid, lane, c, bad);
 #pragma unroll
       for (int r = 0; r < NU; ++r) un[r] = u[r];
       wn = wi;
     }
-    if constexpr (!GS) __syncthreads();  // scratch is reused by the next tile
   }
 }
+
+// ------------------------------------------------------------------------------------
+// fast variant for n_seg <= MAXM: knot loops unrolled, z_i in registers, G_i in LDS.
+// LDS per wave = inputs + 1/T + G  (18.7 KB at n_seg = 10, order 7) -> 8 waves / CU.
+// ------------------------------------------------------------------------------------
+template <int K, int MAXM>
+__global__ void __launch_bounds__(kWave, 2)
+solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+                 int N, int M, double *__restrict__ coef, double *__restrict__ dur,
+                 int32_t *__restrict__ status, int ntiles) {
+  using SW = Sweep<K>;
+  constexpr int NU = SW::NU, NC = SW::NC;
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int lane = threadIdx.x;
+  const int dl = lane >> 2;
+  const int a = lane & 3;
+  const int knots = M - 1;
+  const int wpitch = (M + 1) * 4;
+  const int tpitch = M + 1;
+  double2 *sTr = reinterpret_cast<double2 *>(lds);
+  double *sWraw = lds + (NC / 2) * kTrPitch * 2;
+  double *sTraw = sWraw + 16 * wpitch;
+  double *sX = sTraw + 16 * tpitch;
+  double *sG = sX + 16 * M;
+  (void)knots;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int d_raw = tile * kDronesPerWave + dl;
+    const bool live = d_raw < N;
+    const int d = live ? d_raw : N - 1;
+    const int left = N - tile * kDronesPerWave;
+    const int nvalid = left < kDronesPerWave ? left : kDronesPerWave;
+
+    if (tile != (int)blockIdx.x) __syncthreads();
+    stage_inputs(wp, tt, shared_times, tile, nvalid, wpitch, tpitch, sWraw, sTraw, lane);
+    __syncthreads();
+    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
+    const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
+    const double *lw = sWraw + dloc * wpitch + a;
+    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
+
+    const double t0 = lt[0];
+    double tcur = lt[1];
+    const double w0 = lw[0];
+    double wcur = lw[4];
+    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(w0) && finite64(wcur));
+    double T = tcur - t0;
+    const double Teff = T - t0;
+    bool badtime = !(T > 0.0) || !(Teff > 0.0) || (t0 < 0.0);
+    double x = rcp64(Teff);
+    sX[0 * 16 + dl] = x;
+    SW sw;
+    sw.init(x, wcur - w0);
+
+    double zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
+    double tpre = lt[M >= 2 ? 2 : M];
+    double wpre = lw[(M >= 2 ? 2 : M) * 4];
+#pragma unroll
+    for (int i = 1; i < MAXM; ++i) {
+      if (i < M) {
+        const double tnext = tpre;
+        const double wnext = wpre;
+        {
+          const int ip = (i + 2 <= M) ? i + 2 : M;
+          tpre = lt[ip];
+          wpre = lw[ip * 4];
+        }
+        nonfinite = nonfinite || !finite64(tnext) || !finite64(wnext);
+        T = tnext - tcur;
+        badtime = badtime || !(T > 0.0);
+        x = rcp64(T);
+        sX[i * 16 + dl] = x;
+        double G[NU][NU], z[NU];
+        sw.step(x, wnext - wcur, G, z);
+        double *g = sG + (i - 1) * (NU * NU * 16) + dl;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+#pragma unroll
+          for (int c = 0; c < NU; ++c) g[(r * NU + c) * 16] = G[r][c];
+          zreg[i - 1][r] = z[r];
+        }
+        tcur = tnext;
+        wcur = wnext;
+      }
+    }
+
+    const int st = drone_status(nonfinite, badtime, sw.singular);
+    if (live && a == 0) status[d] = st;
+    const bool bad = st != 0;
+
+    double un[NU], gq[NU][NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) un[r] = 0.0;
+    double wn = wcur;   // w_M
+    double thi = tcur;  // t_M
+    double wq = lw[(M - 1) * 4], tq = lt[M - 1], xq1 = sX[(M - 1) * 16 + dl];
+    {
+      const double *g = sG + ((M >= 3) ? M - 3 : 0) * (NU * NU * 16) + dl;   // G of knot M-2
+#pragma unroll
+      for (int r = 0; r < NU; ++r)
+#pragma unroll
+        for (int c = 0; c < NU; ++c) gq[r][c] = (M >= 3) ? g[(r * NU + c) * 16] : 0.0;
+    }
+#pragma unroll
+    for (int i = MAXM - 1; i >= 0; --i) {
+      if (i < M) {
+        double u[NU];
+        const double wi = wq;
+        const double tlo = tq;
+        const double xi = xq1;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+          double v = (i >= 1) ? zreg[i >= 1 ? i - 1 : 0][r] : 0.0;
+          if (i >= 1 && i < M - 1) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) v = __builtin_fma(-gq[r][c], un[c], v);
+          }
+          u[r] = v;
+        }
+        if (i >= 1) {
+          wq = lw[(i - 1) * 4];
+          tq = lt[i - 1];
+          xq1 = sX[(i - 1) * 16 + dl];
+          if (i >= 2) {   // G of knot i-1 (slot i-2), used by the next iteration
+            const double *g = sG + (i - 2) * (NU * NU * 16) + dl;
+#pragma unroll
+            for (int r = 0; r < NU; ++r)
+#pragma unroll
+              for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
+          }
+        }
+        const double Ti = (i == 0) ? (thi - tlo) - tlo : thi - tlo;
+        thi = tlo;
+        double c[NC];
+        recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
+        if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+        store_segment_coalesced<NC>(sTr, coef + ((size_t)tile * kDronesPerWave * M + i) * (4 * NC),
+                                    (size_t)M * 4 * NC, nvalid, lane, c, bad);
+#pragma unroll
+        for (int r = 0; r < NU; ++r) un[r] = u[r];
+        wn = wi;
+      }
+    }
+  }
+}
+
+constexpr int kRegMaxSeg = 12;   // n_seg <= 12 takes the register-resident variant
 
 template <int K>
 static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const double *t, int shared,
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
+  const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
+  if (M <= kRegMaxSeg) {
+    const size_t nu = K - 1;
+    const size_t lds_bytes = tr_bytes +
+        (solve_input_words(M) + 16 * (size_t)M + 16 * nu * nu * (size_t)(M - 1)) * sizeof(double);
+    hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(ntiles), dim3(kWave), lds_bytes, ctx->stream,
+                       wp, t, shared, N, M, coef, dur, status, ntiles);
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
+  }
   const size_t words = solve_scratch_words(K, M);
+  const size_t lds_bytes = tr_bytes + (words + solve_input_words(M)) * sizeof(double);
   const size_t bytes = words * sizeof(double);
-  if (bytes <= kMaxLdsBytes) {
-    hipLaunchKernelGGL((solve_kernel<K, false>), dim3(ntiles), dim3(kWave), bytes, ctx->stream, wp, t,
+  if (lds_bytes <= kMaxLdsBytes) {
+    hipLaunchKernelGGL((solve_kernel<K, false>), dim3(ntiles), dim3(kWave), lds_bytes, ctx->stream, wp, t,
                        shared, N, M, coef, dur, status, (double *)nullptr, ntiles);
   } else {
     // too many segments for LDS: same recurrence on a global scratch slab,
@@ -375,8 +705,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     if (grid > ntiles) grid = ntiles;
     int rc = ensure(ctx, ctx->scratch, (size_t)grid * bytes);
     if (rc) return rc;
-    hipLaunchKernelGGL((solve_kernel<K, true>), dim3(grid), dim3(kWave), 0, ctx->stream, wp, t, shared,
-                       N, M, coef, dur, status, (double *)ctx->scratch.p, ntiles);
+    hipLaunchKernelGGL((solve_kernel<K, true>), dim3(grid), dim3(kWave), tr_bytes, ctx->stream, wp, t,
+                       shared, N, M, coef, dur, status, (double *)ctx->scratch.p, ntiles);
   }
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;

@@ -60,9 +60,10 @@ const char *msnap_last_hip_error(const msnap_ctx *ctx);
 /* One HIP stream + pinned/device scratch per context. */
 int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments);
 void msnap_destroy(msnap_ctx *ctx);
-/* Borrow an external hipStream_t (e.g. torch's current stream); NULL restores
- * the context's own stream. */
+/* Borrow an external hipStream_t (e.g. torch's current stream; NULL is the HIP
+ * null stream).  msnap_use_own_stream goes back to the context's own stream. */
 int msnap_set_stream(msnap_ctx *ctx, void *hip_stream);
+int msnap_use_own_stream(msnap_ctx *ctx);
 void *msnap_get_stream(msnap_ctx *ctx);
 int msnap_sync(msnap_ctx *ctx);
 /* hipEvent timing on the context's stream (bench.py roofline leg). */
