@@ -328,9 +328,39 @@ def formation_transform(rb_pose: np.ndarray, offsets: np.ndarray,
     for k in range(K):
         for p in range(P):
             q = rb_pose[p, 3:7]
-            out[k, p, 0:3] = quat_rotate(q, offsets[k]) + rb_pose[p, 0:3]
-            out[k, p, 3:7] = quat_mul(q, offset_quat)
+            R = kdl_rotation_from_quaternion(q)
+            out[k, p, 0:3] = R @ offsets[k] + rb_pose[p, 0:3]
+            # drone orientation is identity (drones_traj_generator.py:31,38): the
+            # result frame's rotation is R itself, returned as KDL's GetQuaternion
+            out[k, p, 3:7] = kdl_get_quaternion(R)
     return out
+
+
+def kdl_rotation_from_quaternion(q) -> np.ndarray:
+    """orocos_kdl Rotation::Quaternion(x,y,z,w) (frames.cpp; not vendored in the
+    reference, published algorithm): no normalisation of q."""
+    x, y, z, w = (float(v) for v in q)
+    x2, y2, z2, w2 = x * x, y * y, z * z, w * w
+    return np.array([
+        [w2 + x2 - y2 - z2, 2 * x * y - 2 * w * z, 2 * x * z + 2 * w * y],
+        [2 * x * y + 2 * w * z, w2 - x2 + y2 - z2, 2 * y * z - 2 * w * x],
+        [2 * x * z - 2 * w * y, 2 * y * z + 2 * w * x, w2 - x2 - y2 + z2]])
+
+
+def kdl_get_quaternion(R) -> np.ndarray:
+    """orocos_kdl Rotation::GetQuaternion (frames.cpp): (x, y, z, w)."""
+    trace = R[0, 0] + R[1, 1] + R[2, 2]
+    if trace > 1e-12:
+        s = 0.5 / math.sqrt(trace + 1.0)
+        return np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s, 0.25 / s])
+    if R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2])
+        return np.array([0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s, (R[2, 1] - R[1, 2]) / s])
+    if R[1, 1] > R[2, 2]:
+        s = 2.0 * math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2])
+        return np.array([(R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s, (R[0, 2] - R[2, 0]) / s])
+    s = 2.0 * math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1])
+    return np.array([(R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s, (R[1, 0] - R[0, 1]) / s])
 
 
 # --------------------------------------------------------------------------

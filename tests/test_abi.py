@@ -1,0 +1,75 @@
+"""The C-ABI library loads and exports every symbol include/msnap.h declares.
+No compute is launched here (these run without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    with open(os.path.join(ROOT, "include", "msnap.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(msnap_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exists_and_loads():
+    from drone_path_planning_python_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    lib = _lib.load()
+    assert lib.msnap_version() >= 100
+
+
+def test_every_declared_symbol_is_exported():
+    from drone_path_planning_python_amd import _lib
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/msnap.h but not exported"
+    # and the binding table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_strerror_and_argument_checks_without_gpu():
+    from drone_path_planning_python_amd import _lib
+    lib = _lib.load()
+    assert lib.msnap_strerror(0) == b"ok"
+    assert b"order" in lib.msnap_strerror(-3)
+    h = ctypes.c_void_p()
+    assert lib.msnap_create(ctypes.byref(h), 0, 8, 10) == -3      # MSNAP_EORDER
+    assert lib.msnap_create(ctypes.byref(h), 0, 7, 0) == -4       # MSNAP_ESEGMENTS
+    assert lib.msnap_create(None, 0, 7, 10) == -1                 # MSNAP_EINVAL
+    rc = lib.msnap_create(ctypes.byref(h), 0, 7, 10)
+    if rc == 0:       # a GPU is present: fine, release it
+        lib.msnap_destroy(h)
+    else:
+        assert rc == -6                                           # MSNAP_ENODEVICE, no fallback
+    assert lib.msnap_sync(None) == -1
+    lib.msnap_destroy(None)                                       # tolerated
+
+
+def test_no_cpu_fallback_in_product():
+    """The package must not import anything from oracle/ (parity claims depend on it)."""
+    pkg = os.path.join(ROOT, "drone_path_planning_python_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert "msnap_oracle" not in src and "c_oracle" not in src, fn
+                assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    from drone_path_planning_python_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(OSError):
+        _lib.load()
+    monkeypatch.undo()
+    importlib.reload(_lib)

@@ -1,0 +1,102 @@
+"""The N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercise the
+drone sharding and the all-gather exchange of swarm.formation_pass.  The device
+arithmetic is replaced by the oracle (the checker) behind the same three-method
+interface DeviceCompute offers, so what is tested is the distributed logic:
+partition, padding, gather order, row offsets."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleCompute:
+    """CPU stand-in with DeviceCompute's interface (tests only)."""
+
+    def __init__(self):
+        import msnap_oracle as O
+        self.O = O
+
+    def solve(self, wp, t):
+        coef, dur = self.O.solve_batch_fast(wp.numpy(), t.numpy())
+        return torch.from_numpy(coef), torch.from_numpy(dur), torch.zeros(wp.shape[0], dtype=torch.int32)
+
+    def sample(self, coef, dur, dt, n_samples):
+        return torch.from_numpy(self.O.sample_positions(coef.numpy(), dur.numpy(), dt, n_samples))
+
+    def collide(self, pos_rows, row_offset, pos_all, radius):
+        rows, allp = pos_rows.numpy(), pos_all.numpy()
+        R = rows.shape[0]
+        md = np.full(R, np.inf)
+        partner = np.full(R, -1, dtype=np.int32)
+        for i in range(R):
+            d = allp - rows[i][None]
+            d2 = np.einsum("nsk,nsk->ns", d, d).min(axis=1)
+            d2[row_offset + i] = np.inf
+            j = int(np.argmin(d2))
+            md[i], partner[i] = np.sqrt(d2[j]), j
+        return torch.from_numpy(md), torch.from_numpy(partner), torch.from_numpy((md < 2 * radius).astype(np.int32))
+
+
+def _worker(rank, world, port, n_total, radius, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drone_path_planning_python_amd import swarm
+    from drone_path_planning_python_amd.synthetic import swarm as synth
+    wp, t = synth(3, n_total, 4)
+    wp[:, :, :3] *= 0.2          # crowd the swarm so some pairs do collide
+    lo, hi = swarm.shard_bounds(n_total, world, rank)
+    comp = OracleCompute()
+    coef, dur, _ = comp.solve(torch.from_numpy(wp[lo:hi]), torch.from_numpy(t[lo:hi]))
+    res = swarm.formation_pass(comp, coef, dur, n_total, world, rank, dt=0.25, n_samples=12, radius=radius,
+                               dist=dist, torch=torch)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), lo=res.lo, hi=res.hi, md=res.min_dist.numpy(),
+             partner=res.partner.numpy(), hit=res.hit.numpy(), pos_all=res.positions_all.numpy(),
+             coef=coef.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 10), (2, 11), (3, 10)])
+def test_formation_pass_sharded_equals_unsharded(tmp_path, world, n_total):
+    import msnap_oracle as O
+    from drone_path_planning_python_amd.synthetic import swarm as synth
+    wp, t = synth(3, n_total, 4)
+    wp[:, :, :3] *= 0.2
+    coef, dur = O.solve_batch_fast(wp, t)
+    pos = O.sample_positions(coef, dur, 0.25, 12)
+    md0, _, _ = O.formation_collide(pos, 0.0)
+    radius = 0.5 * float(np.median(md0)) * 1.0001      # about half of the swarm collides
+    md, partner, hit = O.formation_collide(pos, radius)
+    assert hit.any() and not hit.all()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_total, radius, str(tmp_path)), nprocs=world, join=True)
+    seen = 0
+    for r in range(world):
+        d = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        lo, hi = int(d["lo"]), int(d["hi"])
+        seen += hi - lo
+        np.testing.assert_array_equal(d["pos_all"], pos)            # gather order == global order
+        np.testing.assert_array_equal(d["coef"], coef[lo:hi])       # sharded solve == unsharded, bit for bit
+        np.testing.assert_allclose(d["md"], md[lo:hi], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(d["partner"], partner[lo:hi])
+        np.testing.assert_array_equal(d["hit"].astype(bool), hit[lo:hi])
+    assert seen == n_total
