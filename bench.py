@@ -46,6 +46,21 @@ def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
     return n_drones * (8 * 5 * (n_seg + 1) + 8 * n_seg * (1 + 4 * (order + 1)))
 
 
+def pmc_traffic(kernel: str, n_drones: int, n_seg: int):
+    """HBM bytes per launch of `kernel` at this grid, from the committed PMC passes
+    (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X:
+    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction).  None when no matching profile exists."""
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(tp) as f:
+            rec = json.load(f)
+        ent = rec.get(f"{kernel}|{((n_drones + 15) // 16) * 64}|M{n_seg}") or {}
+        return ent.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,27 +153,35 @@ def cpu_baseline(n_seg, order, seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
     from drone_path_planning_python_amd.synthetic import swarm
-    threads = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1))
+    # the box gives one GPU a 16-core share of the host; never oversubscribe it
+    threads = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1, 16))
     wp, t = swarm(2, 256, n_seg)
-    t0 = time.perf_counter()
-    c_oracle.solve_batch(wp, t, ncoef=order + 1, faithful=True, n_threads=threads)
-    probe = max(time.perf_counter() - t0, 1e-4)
-    reps = int(max(1, min(4000, seconds / probe)))
+    # calibrate on ~1 s of work, then size the sample to ~`seconds`
+    reps = 8
+    while True:
+        wpx, tx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1))
+        t0 = time.perf_counter()
+        c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=True, n_threads=threads)
+        probe = time.perf_counter() - t0
+        if probe > 0.5 or reps >= 1 << 14:
+            break
+        reps *= 4
+    reps = int(max(reps, min(1 << 16, reps * seconds / probe)))
     n = 256 * reps
-    wp = np.tile(wp, (reps, 1, 1))
-    t = np.tile(t, (reps, 1))
+    wpx, tx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1))
     t0 = time.perf_counter()
-    _, _, info, used = c_oracle.solve_batch(wp, t, ncoef=order + 1, faithful=True, n_threads=threads)
+    _, _, info, used = c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=True, n_threads=threads)
     dt = time.perf_counter() - t0
+    n1 = 256 * max(1, reps // (4 * threads))
     t1 = time.perf_counter()
-    c_oracle.solve_batch(wp[:256 * max(1, reps // 8)], t[:256 * max(1, reps // 8)], ncoef=order + 1,
-                         faithful=True, n_threads=1)
+    c_oracle.solve_batch(wpx[:n1], tx[:n1], ncoef=order + 1, faithful=True, n_threads=1)
     dt1 = time.perf_counter() - t1
     return {
         "value": n / dt, "unit": "trajectories/s", "cores": int(used), "kind": "port",
         "sample": f"{n} trajectories ({reps} x the 256-drone x {n_seg}-segment batch), dense "
-                  f"{(order + 1) * n_seg}x{(order + 1) * n_seg} LU per axis, OpenMP over drones, {dt:.1f} s",
-        "single_thread_value": 256 * max(1, reps // 8) / dt1,
+                  f"{(order + 1) * n_seg}x{(order + 1) * n_seg} LU with partial pivoting per axis "
+                  f"(C restatement of the reference algorithm), OpenMP over drones, {dt:.1f} s",
+        "single_thread_value": n1 / dt1,
         "host_cpus": os.cpu_count(),
     }
 
@@ -215,7 +238,8 @@ def main():
             "value": nbig / per, "unit": "trajectories/s", "ms_per_launch": per * 1e3,
             "roofline": {"bound": "hbm", "achieved": b / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b / per / 1e9 / HBM_PEAK_GBS, "frac_of_copy_achievable": b / per / 1e9 / HBM_COPY_GBS,
-                         "traffic": None},
+                         "traffic": pmc_traffic(("msnap::solve_kernel_reg<%d, 12>" if M <= 12 else
+                                                 "msnap::solve_kernel<%d, false>") % ((order + 1) // 2), nbig, M)},
         }
         del big
 
@@ -229,16 +253,8 @@ def main():
         total = args.drones * world * args.steps
         per_launch_s = dev_ms_max * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes(args.drones, M, order)
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
-            try:
-                with open(tp) as f:
-                    rec = json.load(f)
-                key = f"{args.drones}x{M}o{order}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kname = ("msnap::solve_kernel_reg<%d, 12>" if M <= 12 else "msnap::solve_kernel<%d, false>") % ((order + 1) // 2)
+        traffic = pmc_traffic(kname, args.drones, M)
         line = {
             "metric": METRIC,
             "value": total / wall_max,
@@ -261,7 +277,8 @@ def main():
                 "launch": "hipGraph of K steps" if use_graph else "eager",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "msnap::solve_kernel<4,false>" if order == 7 else "msnap::solve_kernel<5,false>",
+                "bound": "hbm",
+                "kernel": kname,
                 "achieved": bytes_launch / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": bytes_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic,

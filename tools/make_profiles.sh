@@ -1,0 +1,30 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence for one round.
+#   bash tools/make_profiles.sh r01
+# Writes gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
+set -o pipefail
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=gpurun_out/profiles_${TAG}
+rm -rf "$OUT" && mkdir -p "$OUT"
+
+echo "== 1. kernel trace + stats of the default bench command"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { tail -5 $OUT/bench_under_rocprof.err; exit 1; }
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python3 tools/prof_summary.py $OUT/trace $OUT/kernel_summary.md > /dev/null
+
+echo "== 2. un-profiled bench line (the number to quote)"
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+
+echo "== 3. HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err || { tail -5 $OUT/pmc_$C.err; exit 1; }
+done
+echo "== 4. SQ counters of the solve kernel"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq1.err || exit 1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq2.err || exit 1
+python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.md
+cat $OUT/pmc_summary.md
+# keep the merged-back payload small
+rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2
+tail -c 1500 $OUT/bench.json
