@@ -100,7 +100,7 @@ int msnap_pack_pol_matrix_device(msnap_ctx *ctx, int n_drones, int n_seg,
  * replaces scripts/drones_traj_generator.py:56-89 (K = 2 hard-coded there).
  *   rb_pose [n_poses][7]   x y z qx qy qz qw of the rigid body
  *   offsets [n_offsets][3] body-frame drone positions (identity orientation)
- *   out     [n_offsets][n_poses][7]   p' = R(q) p_k + t,  q' = q (x) (0,0,0,1)
+ *   out     [n_offsets][n_poses][7]   p' = R(q) p_k + t,  q' = quaternion of R(q) (KDL GetQuaternion)
  */
 int msnap_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets,
                               const double *rb_pose, const double *offsets, double *out);
