@@ -260,6 +260,13 @@ __device__ __forceinline__ void store_segment(double *__restrict__ o, double (&c
 // LDS is in-order within a wave; the wavefront-scope fences only pin the
 // compiler's ordering (no vmcnt wait: output stores stay in flight).
 constexpr int kTrPitch = 68;
+#ifdef MSNAP_EXPERIMENT_LINEAR_TILE   // timing experiment only (WRONG layout): a tile-segment is contiguous
+#define MSNAP_SEG_BASE(coef, tile, M, i, NC) ((coef) + ((size_t)(tile) * kDronesPerWave * (M) + (size_t)(i) * kDronesPerWave) * (4 * (NC)))
+#define MSNAP_SEG_STRIDE(M, NC) ((size_t)4 * (NC))
+#else
+#define MSNAP_SEG_BASE(coef, tile, M, i, NC) ((coef) + ((size_t)(tile) * kDronesPerWave * (M) + (i)) * (4 * (NC)))
+#define MSNAP_SEG_STRIDE(M, NC) ((size_t)(M) * 4 * (NC))
+#endif
 template <int NC>
 __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__restrict__ seg_base,
                                                         size_t drone_stride, int nvalid, int lane,
@@ -290,6 +297,61 @@ __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
+}
+
+// Order-7 variant of the same idea without LDS: the 4 axis lanes of a drone hold a
+// 4 x 4 grid of 16-byte pieces (lane = axis, piece = coefficient pair) of the drone's
+// 256-byte block.  Two butterfly stages of quad-local exchanges (DPP quad_perm via
+// __shfl_xor 1 and 2) transpose the grid, after which store q of lane a carries
+// (axis q, pair a): the quad writes 64 contiguous bytes per instruction (whole
+// 64-byte segments), with no LDS round trip and no wait on the critical path.
+template <int CTRL>   // DPP quad_perm control: 0xB1 = lanes xor 1, 0x4E = lanes xor 2
+__device__ __forceinline__ double dpp_quad(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ void quad_exchange(double &A, double &B, bool bit) {
+  // A: value whose piece-index bit is 0, B: bit is 1 (for this stage).  Scalars only:
+  // selecting between array elements would become a runtime-indexed (scratch) array.
+  const double send = bit ? A : B;
+  const double recv = dpp_quad<CTRL>(send);
+  const double na = bit ? recv : A;
+  const double nb = bit ? B : recv;
+  A = na;
+  B = nb;
+}
+
+__device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_base, size_t drone_stride,
+                                                    int nvalid, int lane, const double (&c)[8], bool bad) {
+  const int a = lane & 3;
+  const int dl = lane >> 2;
+  const double nanv = __builtin_nan("");
+  double p0x = bad ? nanv : c[0], p0y = bad ? nanv : c[1], p1x = bad ? nanv : c[2], p1y = bad ? nanv : c[3];
+  double p2x = bad ? nanv : c[4], p2y = bad ? nanv : c[5], p3x = bad ? nanv : c[6], p3y = bad ? nanv : c[7];
+  const bool b0 = (a & 1) != 0, b1 = (a & 2) != 0;
+  quad_exchange<0xB1>(p0x, p1x, b0);
+  quad_exchange<0xB1>(p0y, p1y, b0);
+  quad_exchange<0xB1>(p2x, p3x, b0);
+  quad_exchange<0xB1>(p2y, p3y, b0);
+  quad_exchange<0x4E>(p0x, p2x, b1);
+  quad_exchange<0x4E>(p0y, p2y, b1);
+  quad_exchange<0x4E>(p1x, p3x, b1);
+  quad_exchange<0x4E>(p1y, p3y, b1);
+  // now piece q = coefficient pair `a` of axis q
+  bool ok = dl < nvalid;
+#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
+  ok = ok && (p0x == 12345.678);
+#endif
+  if (ok) {
+    double *o = seg_base + (size_t)dl * drone_stride + a * 2;
+    *reinterpret_cast<double2 *>(o + 0) = make_double2(p0x, p0y);
+    *reinterpret_cast<double2 *>(o + 8) = make_double2(p1x, p1y);
+    *reinterpret_cast<double2 *>(o + 16) = make_double2(p2x, p2y);
+    *reinterpret_cast<double2 *>(o + 24) = make_double2(p3x, p3y);
+  }
 }
 
 // dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
@@ -520,8 +582,8 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
       double c[NC];
       recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
       if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-      store_segment_coalesced<NC>(sTr, coef + ((size_t)tile * kDronesPerWave * M + i) * (4 * NC),
-                                  (size_t)M * 4 * NC, nvalid, lane, c, bad);
+      store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
+                                  lane, c, bad);
 #pragma unroll
       for (int r = 0; r < NU; ++r) un[r] = u[r];
       wn = wi;
@@ -534,7 +596,7 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
 // LDS per wave = inputs + 1/T + G  (18.7 KB at n_seg = 10, order 7) -> 8 waves / CU.
 // ------------------------------------------------------------------------------------
 template <int K, int MAXM>
-__global__ void __launch_bounds__(kWave, 2)
+__global__ void __launch_bounds__(kWave, (K <= 4 ? 2 : 1))   // order 9 needs > 256 VGPRs to stay spill-free
 solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
                  int N, int M, double *__restrict__ coef, double *__restrict__ dur,
                  int32_t *__restrict__ status, int ntiles) {
@@ -546,15 +608,16 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   const int lane = threadIdx.x;
   const int dl = lane >> 2;
   const int a = lane & 3;
-  const int knots = M - 1;
   const int wpitch = (M + 1) * 4;
   const int tpitch = M + 1;
-  double2 *sTr = reinterpret_cast<double2 *>(lds);
-  double *sWraw = lds + (NC / 2) * kTrPitch * 2;
+  // LDS: [ inputs Wraw | Traw ] -- dead after the forward sweep, then reused as the output
+  //      transpose image -- followed by G[M-2][NU*NU][16] (G of the last knot is never read)
+  double *sWraw = lds;
   double *sTraw = sWraw + 16 * wpitch;
-  double *sX = sTraw + 16 * tpitch;
-  double *sG = sX + 16 * M;
-  (void)knots;
+  double2 *sTr = reinterpret_cast<double2 *>(lds);
+  const int in_words = 16 * wpitch + 16 * tpitch;
+  const int tr_words = (NC / 2) * kTrPitch * 2;
+  double *sG = lds + (in_words > tr_words ? in_words : tr_words);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d_raw = tile * kDronesPerWave + dl;
@@ -571,48 +634,50 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     const double *lw = sWraw + dloc * wpitch + a;
     const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
 
+    // per-lane copies of the path: waypoints, segment lengths and their reciprocals stay in
+    // registers for the backward sweep (knot loops are unrolled, so the indices are static)
+    double wreg[MAXM + 1], Treg[MAXM], xreg[MAXM], zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
+
     const double t0 = lt[0];
     double tcur = lt[1];
-    const double w0 = lw[0];
-    double wcur = lw[4];
-    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(w0) && finite64(wcur));
-    double T = tcur - t0;
-    const double Teff = T - t0;
-    bool badtime = !(T > 0.0) || !(Teff > 0.0) || (t0 < 0.0);
-    double x = rcp64(Teff);
-    sX[0 * 16 + dl] = x;
+    wreg[0] = lw[0];
+    wreg[1] = lw[4];
+    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(wreg[0]) && finite64(wreg[1]));
+    const double T0 = tcur - t0;
+    Treg[0] = T0 - t0;            // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
+    bool badtime = !(T0 > 0.0) || !(Treg[0] > 0.0) || (t0 < 0.0);
+    xreg[0] = rcp64(Treg[0]);
     SW sw;
-    sw.init(x, wcur - w0);
+    sw.init(xreg[0], wreg[1] - wreg[0]);
 
-    double zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
     double tpre = lt[M >= 2 ? 2 : M];
     double wpre = lw[(M >= 2 ? 2 : M) * 4];
 #pragma unroll
     for (int i = 1; i < MAXM; ++i) {
       if (i < M) {
         const double tnext = tpre;
-        const double wnext = wpre;
+        wreg[i + 1] = wpre;
         {
           const int ip = (i + 2 <= M) ? i + 2 : M;
           tpre = lt[ip];
           wpre = lw[ip * 4];
         }
-        nonfinite = nonfinite || !finite64(tnext) || !finite64(wnext);
-        T = tnext - tcur;
-        badtime = badtime || !(T > 0.0);
-        x = rcp64(T);
-        sX[i * 16 + dl] = x;
+        nonfinite = nonfinite || !finite64(tnext) || !finite64(wreg[i + 1]);
+        Treg[i] = tnext - tcur;
+        badtime = badtime || !(Treg[i] > 0.0);
+        xreg[i] = rcp64(Treg[i]);
         double G[NU][NU], z[NU];
-        sw.step(x, wnext - wcur, G, z);
-        double *g = sG + (i - 1) * (NU * NU * 16) + dl;
+        sw.step(xreg[i], wreg[i + 1] - wreg[i], G, z);
+        if (i < M - 1) {
+          double *g = sG + (i - 1) * (NU * NU * 16) + dl;
 #pragma unroll
-        for (int r = 0; r < NU; ++r) {
+          for (int r = 0; r < NU; ++r)
 #pragma unroll
-          for (int c = 0; c < NU; ++c) g[(r * NU + c) * 16] = G[r][c];
-          zreg[i - 1][r] = z[r];
+            for (int c = 0; c < NU; ++c) g[(r * NU + c) * 16] = G[r][c];
         }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) zreg[i - 1][r] = z[r];
         tcur = tnext;
-        wcur = wnext;
       }
     }
 
@@ -620,26 +685,18 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     if (live && a == 0) status[d] = st;
     const bool bad = st != 0;
 
+    // ---------------- backward sweep + recovery: registers + one G block per knot ----------------
     double un[NU], gq[NU][NU];
 #pragma unroll
-    for (int r = 0; r < NU; ++r) un[r] = 0.0;
-    double wn = wcur;   // w_M
-    double thi = tcur;  // t_M
-    double wq = lw[(M - 1) * 4], tq = lt[M - 1], xq1 = sX[(M - 1) * 16 + dl];
-    {
-      const double *g = sG + ((M >= 3) ? M - 3 : 0) * (NU * NU * 16) + dl;   // G of knot M-2
+    for (int r = 0; r < NU; ++r) {
+      un[r] = 0.0;
 #pragma unroll
-      for (int r = 0; r < NU; ++r)
-#pragma unroll
-        for (int c = 0; c < NU; ++c) gq[r][c] = (M >= 3) ? g[(r * NU + c) * 16] : 0.0;
+      for (int c = 0; c < NU; ++c) gq[r][c] = 0.0;
     }
 #pragma unroll
     for (int i = MAXM - 1; i >= 0; --i) {
       if (i < M) {
         double u[NU];
-        const double wi = wq;
-        const double tlo = tq;
-        const double xi = xq1;
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
           double v = (i >= 1) ? zreg[i >= 1 ? i - 1 : 0][r] : 0.0;
@@ -649,28 +706,23 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
           }
           u[r] = v;
         }
-        if (i >= 1) {
-          wq = lw[(i - 1) * 4];
-          tq = lt[i - 1];
-          xq1 = sX[(i - 1) * 16 + dl];
-          if (i >= 2) {   // G of knot i-1 (slot i-2), used by the next iteration
-            const double *g = sG + (i - 2) * (NU * NU * 16) + dl;
+        if (i >= 2) {   // G of knot i-1 (slot i-2), used by the next iteration (i-1 < M-1 always)
+          const double *g = sG + (i - 2) * (NU * NU * 16) + dl;
 #pragma unroll
-            for (int r = 0; r < NU; ++r)
+          for (int r = 0; r < NU; ++r)
 #pragma unroll
-              for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
-          }
+            for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
         }
-        const double Ti = (i == 0) ? (thi - tlo) - tlo : thi - tlo;
-        thi = tlo;
         double c[NC];
-        recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
+        recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], Treg[i], xreg[i], u, un, c);
         if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-        store_segment_coalesced<NC>(sTr, coef + ((size_t)tile * kDronesPerWave * M + i) * (4 * NC),
-                                    (size_t)M * 4 * NC, nvalid, lane, c, bad);
+        if constexpr (NC == 8)
+          store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
+        else
+          store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
+                                      lane, c, bad);
 #pragma unroll
         for (int r = 0; r < NU; ++r) un[r] = u[r];
-        wn = wi;
       }
     }
   }
@@ -685,8 +737,9 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
   if (M <= kRegMaxSeg) {
     const size_t nu = K - 1;
-    const size_t lds_bytes = tr_bytes +
-        (solve_input_words(M) + 16 * (size_t)M + 16 * nu * nu * (size_t)(M - 1)) * sizeof(double);
+    const size_t in_bytes = solve_input_words(M) * sizeof(double);
+    const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +
+                             16 * nu * nu * (size_t)(M > 2 ? M - 2 : 0) * sizeof(double);
     hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(ntiles), dim3(kWave), lds_bytes, ctx->stream,
                        wp, t, shared, N, M, coef, dur, status, ntiles);
     MSNAP_HIP(ctx, hipGetLastError());
