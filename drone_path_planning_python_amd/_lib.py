@@ -36,6 +36,10 @@ SIGNATURES = {
     "msnap_timer_stop": (_I, [_VP, c_float_p]),
     "msnap_solve_batch": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "msnap_solve_batch_device": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
+    "msnap_grid_prepare": (_I, [_VP, _I, _VP]),
+    "msnap_grid_prepare_device": (_I, [_VP, _I, _VP]),
+    "msnap_solve_grid": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
+    "msnap_solve_grid_device": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
     "msnap_pack_pol_matrix": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_pack_pol_matrix_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_formation_transform": (_I, [_VP, _I, _I, _VP, _VP, _VP]),

@@ -127,6 +127,53 @@ class Context:
                 self._h, int(n_drones), int(n_seg), _ptr(wp), _ptr(t), int(bool(shared_times)),
                 _ptr(coef), _ptr(dur), _ptr(status)))
 
+    # ---- shared time grid (K2: fp64 MFMA GEMM) ---------------------------------
+    def prepare_grid(self, t):
+        """Build the operator of the shared time grid t [m] (host array)."""
+        t, pt = _host(t, np.float64)
+        if t.ndim != 1 or t.shape[0] < 2:
+            raise ValueError("t must be [m], m >= 2")
+        with self._lock:
+            self._ck(self._lib.msnap_grid_prepare(self._h, t.shape[0] - 1, pt))
+        self._grid_m = t.shape[0]
+        self._grid_host = t.copy()
+
+    def ensure_grid(self, t):
+        """prepare_grid(t) unless the context already holds exactly this grid."""
+        t = np.ascontiguousarray(t, dtype=np.float64)
+        g = getattr(self, "_grid_host", None)
+        if g is None or g.shape != t.shape or not np.array_equal(g, t):
+            self.prepare_grid(t)
+
+    def prepare_grid_device(self, n_seg, t):
+        with self._lock:
+            self._ck(self._lib.msnap_grid_prepare_device(self._h, int(n_seg), _ptr(t)))
+        self._grid_m = int(n_seg) + 1
+        self._grid_host = None
+
+    def solve_grid(self, wp):
+        """wp [N, m, 4] on the prepared grid -> coef, dur, status (as solve_batch)."""
+        wp, pwp = _host(wp, np.float64)
+        m = getattr(self, "_grid_m", None)
+        if m is None:
+            _lib.check(self._lib, self._h, -7)
+        if wp.ndim != 3 or wp.shape[1:] != (m, 4):
+            raise ValueError(f"wp must be [N, {m}, 4] for the prepared grid")
+        N, M = wp.shape[0], m - 1
+        coef = np.empty((N, M, 4, self.ncoef), dtype=np.float64)
+        dur = np.empty((N, M), dtype=np.float64)
+        status = np.empty((N,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_solve_grid(self._h, N, pwp, coef.ctypes.data_as(ctypes.c_void_p),
+                                               dur.ctypes.data_as(ctypes.c_void_p),
+                                               status.ctypes.data_as(ctypes.c_void_p)))
+        return coef, dur, status
+
+    def solve_grid_device(self, n_drones, wp, coef, dur, status):
+        with self._lock:
+            self._ck(self._lib.msnap_solve_grid_device(self._h, int(n_drones), _ptr(wp), _ptr(coef), _ptr(dur),
+                                                      _ptr(status)))
+
     # ---- a7 pack ---------------------------------------------------------------
     def pack_pol_matrix(self, coef, dur):
         coef, pc = _host(coef, np.float64)

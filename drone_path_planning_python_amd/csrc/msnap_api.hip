@@ -55,6 +55,7 @@ const char *msnap_strerror(int code) {
     case MSNAP_ESEGMENTS: return "segment count out of range for this context";
     case MSNAP_ENOMEM: return "out of memory";
     case MSNAP_ENODEVICE: return "no usable gfx950 device";
+    case MSNAP_ENOGRID: return "no time grid prepared on this context (msnap_grid_prepare)";
     default: return "unknown msnap error";
   }
 }
@@ -98,6 +99,8 @@ void msnap_destroy(msnap_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
+  for (msnap::DevBuf *b : {&ctx->grid_t, &ctx->grid_wp, &ctx->grid_op, &ctx->grid_dur, &ctx->grid_status, &ctx->grid_frag})
+    if (b->p) (void)hipFree(b->p);
   for (auto &b : ctx->stage)
     if (b.p) (void)hipFree(b.p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -174,6 +177,63 @@ int msnap_solve_batch(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
   rc = launch_solve(ctx, n_drones, n_seg, (const double *)ctx->stage[0].p, (const double *)ctx->stage[1].p,
                     shared_times ? 1 : 0, (double *)ctx->stage[2].p, (double *)ctx->stage[3].p,
                     (int32_t *)ctx->stage[4].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(coef, ctx->stage[2].p, b_coef, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(dur, ctx->stage[3].p, b_dur, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(status, ctx->stage[4].p, b_st, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------ shared grid (K2)
+int msnap_grid_prepare_device(msnap_ctx *ctx, int n_seg, const double *t) {
+  if (!ctx || !t) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_grid_prepare(ctx, n_seg, t, 1);
+}
+
+int msnap_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t) {
+  if (!ctx || !t) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  rc = launch_grid_prepare(ctx, n_seg, t, 0);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // t is pageable host memory
+  return MSNAP_OK;
+}
+
+int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+                            int32_t *status) {
+  if (!ctx || n_drones < 0) return MSNAP_EINVAL;
+  if (!ctx->grid_ready) return MSNAP_ENOGRID;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_solve_grid(ctx, n_drones, wp, coef, dur, status);
+}
+
+int msnap_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+                     int32_t *status) {
+  if (!ctx || n_drones < 0) return MSNAP_EINVAL;
+  if (!ctx->grid_ready) return MSNAP_ENOGRID;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const int n_seg = ctx->grid_seg;
+  const size_t N = n_drones, m = (size_t)n_seg + 1, nc = ctx->order + 1;
+  const size_t b_wp = N * m * 4 * 8;
+  const size_t b_coef = N * n_seg * 4 * nc * 8, b_dur = N * n_seg * 8, b_st = N * 4;
+  int rc;
+  if ((rc = ensure(ctx, ctx->stage[0], b_wp))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[2], b_coef))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[3], b_dur))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[4], b_st))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, wp, b_wp, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_solve_grid(ctx, n_drones, (const double *)ctx->stage[0].p, (double *)ctx->stage[2].p,
+                         (double *)ctx->stage[3].p, (int32_t *)ctx->stage[4].p);
   if (rc) return rc;
   MSNAP_HIP(ctx, hipMemcpyAsync(coef, ctx->stage[2].p, b_coef, hipMemcpyDeviceToHost, ctx->stream));
   MSNAP_HIP(ctx, hipMemcpyAsync(dur, ctx->stage[3].p, b_dur, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,225 @@
+// K2 -- shared-time-grid fast path: one dense fp64 GEMM on the matrix cores.
+//
+// When every drone of a batch uses the same time grid -- the reference's own
+// usage: path_to_pol gives all paths the uniform grid t_i = i*10/n
+// (scripts/drones_pols_generator.py:44-46,56) -- the collocation matrix A of
+// calculate_trajectory1D (src/optimizations/calculatingTrajectories.py:48-131)
+// is the same for every drone and axis, and b = S w is linear in the waypoint
+// values, so all coefficients are
+//        C[(drone,axis)][(seg,coef)] = sum_j  W[(drone,axis)][j] * Gop[j][(seg,coef)]
+// with Gop = (A^-1 S)^T of shape (M+1) x (M*ncoef).  msnap_grid_prepare computes
+// Gop ON THE GPU by running the K1 solve on the M+1 unit waypoint vectors (so it
+// inherits K1's parity), and msnap_solve_grid is then a single
+// v_mfma_f64_16x16x4_f64 GEMM -- the one genuinely dense contraction of the path,
+// and the only place MFMA is used.
+//
+// Tiling (wave64): an MFMA row tile is 16 (drone,axis) rows = 4 drones x 4 axes,
+// a column tile 16 flat (segment,coef) columns, the k dimension the M+1 waypoints
+// in steps of 4.  f64 operand maps (cdna_hip_programming.md 3): A[row=l&15][k=l>>4],
+// B[k=l>>4][col=l&15], D row=(l>>4)+4*reg, col=l&15 -- with row = 4*drone+axis the
+// accumulator register index is the drone and lane>>4 the axis, so one store
+// instruction (fixed reg) covers [2 segments][4 axes][8 coefs] = 512 contiguous
+// bytes of one drone at order 7.  Every wave keeps the whole Gop in registers
+// (B fragments) and streams row tiles: the kernel is bound by the output stores.
+#include "msnap_internal.h"
+
+namespace msnap {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kGridMaxCT = 8;   // column tiles kept in registers (16 columns each)
+constexpr int kGridMaxKS = 4;   // k steps (4 waypoints each): M + 1 <= 16
+
+// wp'[p][i][a] = 1 if i == 4p + a else 0 : the M+1 unit waypoint vectors, 4 per pseudo-drone
+__global__ void __launch_bounds__(256)
+unit_wp_kernel(double *__restrict__ wp, int P, int m) {
+  const int total = P * m * 4;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int a = idx & 3;
+    const int i = (idx >> 2) % m;
+    const int p = (idx >> 2) / m;
+    wp[idx] = (i == 4 * p + a) ? 1.0 : 0.0;
+  }
+}
+
+// Gop in MFMA B-fragment order: frag[(ct*kGridMaxKS + ks)*64 + lane] = Gop[j = 4*ks + lane>>4][c = 16*ct + lane&15]
+// (zero outside), so the GEMM prologue is nct*nks coalesced loads with no index arithmetic.
+__global__ void __launch_bounds__(kWave)
+pack_gop_kernel(const double *__restrict__ gop /* [P][M][4][NC] */, int M, int NC, double *__restrict__ frag) {
+  const int lane = threadIdx.x;
+  const int ct = blockIdx.x / kGridMaxKS, ks = blockIdx.x % kGridMaxKS;
+  const int j = 4 * ks + (lane >> 4);
+  const int c = 16 * ct + (lane & 15);
+  double v = 0.0;
+  if (j < M + 1 && c < M * NC) {
+    const int seg = c / NC, kc = c - seg * NC;
+    v = gop[(((size_t)(j >> 2) * M + seg) * 4 + (j & 3)) * NC + kc];
+  }
+  frag[(size_t)blockIdx.x * kWave + lane] = v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+template <int NC>
+__global__ void __launch_bounds__(kWave)
+grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /* packed B fragments */,
+                 const double *__restrict__ gdur /* [M] */, const int32_t *__restrict__ gstatus, int N, int M,
+                 int nct, int nks, double *__restrict__ coef, double *__restrict__ dur,
+                 int32_t *__restrict__ status, int nrt) {
+  const int lane = threadIdx.x;
+  const int col = lane & 15;
+  const int kq = lane >> 4;          // k offset inside a step (A/B operands), axis (D)
+  const int m = M + 1;
+  const int ncols = M * NC;
+  const int grid_st = gstatus[0];
+
+  // B fragments (pre-packed by pack_gop_kernel): Gop[j = 4*ks + kq][c = 16*ct + col]
+  double bf[kGridMaxCT][kGridMaxKS];
+#pragma unroll
+  for (int ct = 0; ct < kGridMaxCT; ++ct) {
+#pragma unroll
+    for (int ks = 0; ks < kGridMaxKS; ++ks)
+      bf[ct][ks] = (ct < nct && ks < nks) ? gop[(size_t)(ct * kGridMaxKS + ks) * kWave + lane] : 0.0;
+  }
+
+  // A fragments of a row tile: W[row = lane&15 -> (drone 4*rt + row>>2, axis row&3)][j = 4*ks + kq]
+  auto load_a = [&](int rt, double (&af)[kGridMaxKS]) {
+    const int drow = rt * 4 + (col >> 2);
+    const int dclamp = drow < N ? drow : N - 1;
+    const double *wrow = wp + (size_t)dclamp * m * 4 + (col & 3);
+#pragma unroll
+    for (int ks = 0; ks < kGridMaxKS; ++ks) {
+      const int j = 4 * ks + kq;
+      af[ks] = (ks < nks && j < m) ? wrow[(size_t)j * 4] : 0.0;
+    }
+  };
+
+  double anext[kGridMaxKS];
+  if ((int)blockIdx.x < nrt) load_a(blockIdx.x, anext);
+  for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
+    const int d0 = rt * 4;
+    double af[kGridMaxKS];
+    bool nonfin = false;
+#pragma unroll
+    for (int ks = 0; ks < kGridMaxKS; ++ks) {
+      af[ks] = anext[ks];
+      nonfin = nonfin || !__builtin_isfinite(af[ks]);
+    }
+    // the next tile's waypoints are in flight while this tile's MFMAs and stores run
+    if (rt + (int)gridDim.x < nrt) load_a(rt + gridDim.x, anext);
+    // per-drone non-finite flag: rows 4*dl .. 4*dl+3 of the tile, any k
+    const unsigned long long bal = __ballot(nonfin);
+
+#pragma unroll
+    for (int ct = 0; ct < kGridMaxCT; ++ct) {
+      if (ct < nct) {
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < kGridMaxKS; ++ks) {
+          if (ks < nks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ct][ks], acc, 0, 0, 0);
+        }
+        // pair exchange (lanes l, l^1 hold adjacent columns): afterwards an even lane owns
+        // columns (c, c+1) of drones 0 and 2, an odd lane the same columns of drones 1 and 3,
+        // so every lane issues two 16-byte stores instead of four 8-byte ones
+        const bool odd = (lane & 1) != 0;
+        const double s0 = dpp_quad_f64<0xB1>(odd ? acc[0] : acc[1]);
+        const double s1 = dpp_quad_f64<0xB1>(odd ? acc[2] : acc[3]);
+        const double lo0 = odd ? s0 : acc[0], hi0 = odd ? acc[1] : s0;   // drone (odd ? 1 : 0)
+        const double lo1 = odd ? s1 : acc[2], hi1 = odd ? acc[3] : s1;   // drone (odd ? 3 : 2)
+        const int c = 16 * ct + (col & ~1);
+        const int seg = c / NC, kc = c - seg * NC;     // NC is even: a pair never straddles a segment
+        if (c < ncols) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int r = 2 * h + (odd ? 1 : 0);       // drone inside the tile, kq = axis
+            const int d = d0 + r;
+            // lanes of drone r as A rows: (lane & 12) == 4*r
+            const unsigned long long dm = 0x000F000F000F000FULL << (4 * r);
+            const bool bad = (grid_st != 0) || ((bal & dm) != 0ULL);
+            double2 v = h == 0 ? make_double2(lo0, hi0) : make_double2(lo1, hi1);
+            if (bad) v = make_double2(__builtin_nan(""), __builtin_nan(""));
+            if (d < N) *reinterpret_cast<double2 *>(coef + (((size_t)d * M + seg) * 4 + kq) * NC + kc) = v;
+          }
+        }
+      }
+    }
+    // durations and status of the 4 drones
+    for (int e = lane; e < 4 * M; e += kWave) {
+      const int r = e / M;
+      if (d0 + r < N) dur[(size_t)d0 * M + e] = gdur[e - r * M];
+    }
+    if (lane < 4 && d0 + lane < N) {
+      const unsigned long long dm = 0x000F000F000F000FULL << (4 * lane);
+      status[d0 + lane] = (bal & dm) ? MSNAP_ST_NONFINITE : grid_st;
+    }
+  }
+}
+
+int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device) {
+  const int m = n_seg + 1;
+  const int nc = ctx->order + 1;
+  const int P = (m + 3) / 4;
+  int rc;
+  if ((rc = ensure(ctx, ctx->grid_t, (size_t)m * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->grid_wp, (size_t)P * m * 4 * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->grid_op, (size_t)P * n_seg * 4 * nc * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->grid_dur, (size_t)P * n_seg * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->grid_status, (size_t)P * 4))) return rc;
+  ctx->grid_ready = 0;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->grid_t.p, t, (size_t)m * 8,
+                                t_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(unit_wp_kernel, dim3((P * m * 4 + 255) / 256), dim3(256), 0, ctx->stream,
+                     (double *)ctx->grid_wp.p, P, m);
+  MSNAP_HIP(ctx, hipGetLastError());
+  rc = launch_solve(ctx, P, n_seg, (const double *)ctx->grid_wp.p, (const double *)ctx->grid_t.p, 1,
+                    (double *)ctx->grid_op.p, (double *)ctx->grid_dur.p, (int32_t *)ctx->grid_status.p);
+  if (rc) return rc;
+  if ((rc = ensure(ctx, ctx->grid_frag, (size_t)kGridMaxCT * kGridMaxKS * kWave * 8))) return rc;
+  if (grid_gemm_supported(ctx, n_seg)) {
+    hipLaunchKernelGGL(pack_gop_kernel, dim3(kGridMaxCT * kGridMaxKS), dim3(kWave), 0, ctx->stream,
+                       (const double *)ctx->grid_op.p, n_seg, nc, (double *)ctx->grid_frag.p);
+    MSNAP_HIP(ctx, hipGetLastError());
+  }
+  ctx->grid_seg = n_seg;
+  ctx->grid_ready = 1;
+  return MSNAP_OK;
+}
+
+bool grid_gemm_supported(const msnap_ctx *ctx, int n_seg) {
+  const int nc = ctx->order + 1;
+  const int nct = (n_seg * nc + 15) / 16;
+  const int nks = (n_seg + 1 + 3) / 4;
+  return nct <= kGridMaxCT && nks <= kGridMaxKS;
+}
+
+int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+                      int32_t *status) {
+  const int M = ctx->grid_seg;
+  if (!grid_gemm_supported(ctx, M)) {
+    // operator too large for the register-resident GEMM: the K1 solve on the shared grid
+    return launch_solve(ctx, n_drones, M, wp, (const double *)ctx->grid_t.p, 1, coef, dur, status);
+  }
+  const int nc = ctx->order + 1;
+  const int nct = (M * nc + 15) / 16;
+  const int nks = (M + 1 + 3) / 4;
+  const int nrt = (n_drones + 3) / 4;
+  int grid = ctx->n_cu * 8;
+  if (grid > nrt) grid = nrt;
+  if (nc == 8)
+    hipLaunchKernelGGL((grid_gemm_kernel<8>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,
+                       (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,
+                       (const int32_t *)ctx->grid_status.p, n_drones, M, nct, nks, coef, dur, status, nrt);
+  else
+    hipLaunchKernelGGL((grid_gemm_kernel<10>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,
+                       (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,
+                       (const int32_t *)ctx->grid_status.p, n_drones, M, nct, nks, coef, dur, status, nrt);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+}  // namespace msnap

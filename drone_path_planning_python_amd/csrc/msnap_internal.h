@@ -46,6 +46,10 @@ struct msnap_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   msnap::DevBuf scratch;   // global-memory scratch for n_seg too large for LDS
   msnap::DevBuf stage[8];  // device staging for the host-pointer entry points
+  // shared-time-grid operator (K2): built by msnap_grid_prepare
+  msnap::DevBuf grid_t, grid_wp, grid_op, grid_dur, grid_status, grid_frag;
+  int grid_seg = 0;
+  int grid_ready = 0;
   char hip_err[256] = {0};
 };
 
@@ -75,5 +79,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
 int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
                       const double *tris, double radius, double *min_dist, int32_t *hit);
 int solve_kernel_setup(msnap_ctx *ctx);
+int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device);
+int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+                      int32_t *status);
+bool grid_gemm_supported(const msnap_ctx *ctx, int n_seg);
 
 }  // namespace msnap

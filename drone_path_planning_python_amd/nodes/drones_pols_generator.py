@@ -66,7 +66,9 @@ def paths_to_pols(paths: Sequence, ctx: Context | None = None):
     """Batched path_to_pol: returns (matrix f32 [N, M, 33], coef, dur)."""
     ctx = ctx or default_context(7)
     wp, t = paths_to_waypoints(paths)
-    coef, dur, status = ctx.solve_batch(wp, t)
+    # every path of the node shares the uniform grid: one operator, one MFMA GEMM per batch
+    ctx.ensure_grid(t)
+    coef, dur, status = ctx.solve_grid(wp)
     for k in range(len(paths)):
         raise_for_status(int(status[k]), t)
     return ctx.pack_pol_matrix(coef, dur), coef, dur

@@ -43,7 +43,8 @@ enum msnap_error {
   MSNAP_EORDER = -3,      /* order is not 7 or 9                              */
   MSNAP_ESEGMENTS = -4,   /* n_seg < 1 or n_seg > max_segments of the context */
   MSNAP_ENOMEM = -5,      /* host or device allocation failed                 */
-  MSNAP_ENODEVICE = -6    /* no gfx950 device / device_id out of range        */
+  MSNAP_ENODEVICE = -6,   /* no gfx950 device / device_id out of range        */
+  MSNAP_ENOGRID = -7      /* msnap_solve_grid without a prepared grid          */
 };
 
 enum msnap_status {       /* per-drone, written to status[]                   */
@@ -86,6 +87,24 @@ int msnap_solve_batch(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
 int msnap_solve_batch_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
                              const double *t, int shared_times, double *coef,
                              double *dur, int32_t *status);
+
+/* ---- a1/a2 on a SHARED time grid: one fp64 MFMA GEMM -----------------------------
+ * The reference's own usage: path_to_pol gives every drone the uniform grid
+ * t_i = i*10/n (scripts/drones_pols_generator.py:44-46,56), so the matrix of
+ * calculate_trajectory1D (src/optimizations/calculatingTrajectories.py:48-131) is
+ * shared and the coefficients are linear in the waypoints.
+ *   msnap_grid_prepare  builds the (n_seg+1) x (n_seg*ncoef) operator for t on
+ *                       the GPU (the solve kernel on unit waypoint vectors);
+ *   msnap_solve_grid    applies it to n_drones waypoint sets: same outputs as
+ *                       msnap_solve_batch(.., t, shared_times = 1, ..).
+ * The operator stays valid until the next msnap_grid_prepare on this context.
+ */
+int msnap_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t /* host [n_seg+1] */);
+int msnap_grid_prepare_device(msnap_ctx *ctx, int n_seg, const double *t /* device */);
+int msnap_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+                     int32_t *status);
+int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, const double *wp, double *coef,
+                            double *dur, int32_t *status);
 
 /* ---- a7: the float32 [T | x | y | z | yaw] matrix of path_to_pol -----------------
  * replaces scripts/drones_pols_generator.py:63-77.
