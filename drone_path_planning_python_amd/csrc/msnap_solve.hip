@@ -414,6 +414,60 @@ __device__ __forceinline__ void stage_inputs(const double *__restrict__ wp, cons
   }
 }
 
+// the same sweep split in two for software pipelining across tiles (n_seg <= 12: one round):
+// the loads of tile k+1 are issued near the end of tile k and land in LDS at the top of k+1
+template <int MAXM>
+struct StageRegs {
+  static constexpr int UW = (MAXM + 2) / 2;   // ceil(16*(MAXM+1)*4/2 / 64) 16-byte loads per lane
+  static constexpr int UT = (MAXM + 4) / 4;   // ceil(16*(MAXM+1) / 64) 8-byte loads per lane
+  double2 vw[UW];
+  double vt[UT];
+};
+
+template <int MAXM>
+__device__ __forceinline__ void stage_load_once(const double *__restrict__ wp, const double *__restrict__ tt,
+                                                int shared_times, int tile, int nvalid, int wpitch, int tpitch,
+                                                int lane, StageRegs<MAXM> &r) {
+  constexpr int kStageUW = StageRegs<MAXM>::UW, kStageUT = StageRegs<MAXM>::UT;
+  const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kDronesPerWave * wpitch);
+  const int wcnt = nvalid * wpitch / 2;
+  const double *tsrc = shared_times ? tt : tt + (size_t)tile * kDronesPerWave * tpitch;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < kStageUW; ++u) {
+    const int e = u * kWave + lane;
+    r.vw[u] = wsrc[e < wcnt ? e : wcnt - 1];
+  }
+#pragma unroll
+  for (int u = 0; u < kStageUT; ++u) {
+    const int f = u * kWave + lane;
+    r.vt[u] = tsrc[f < tcnt ? f : tcnt - 1];
+  }
+}
+
+template <int MAXM>
+__device__ __forceinline__ void stage_store_once(int shared_times, int nvalid, int wpitch, int tpitch,
+                                                 double *sWraw, double *sTraw, int lane, StageRegs<MAXM> &r) {
+  constexpr int kStageUW = StageRegs<MAXM>::UW, kStageUT = StageRegs<MAXM>::UT;
+  double2 *wdst = reinterpret_cast<double2 *>(sWraw);
+  const int wcnt = nvalid * wpitch / 2;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < kStageUW; ++u) asm volatile("" : "+v"(r.vw[u].x), "+v"(r.vw[u].y));
+#pragma unroll
+  for (int u = 0; u < kStageUT; ++u) asm volatile("" : "+v"(r.vt[u]));
+#pragma unroll
+  for (int u = 0; u < kStageUW; ++u) {
+    const int e = u * kWave + lane;
+    if (e < wcnt) wdst[e] = r.vw[u];
+  }
+#pragma unroll
+  for (int u = 0; u < kStageUT; ++u) {
+    const int f = u * kWave + lane;
+    if (f < tcnt) sTraw[f] = r.vt[u];
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // generic variant: rolled loops, G_i / z_i stashed in LDS (GS = false) or on a
 // global slab (GS = true)
@@ -619,15 +673,23 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   const int tr_words = (NC / 2) * kTrPitch * 2;
   double *sG = lds + (in_words > tr_words ? in_words : tr_words);
 
+  auto tile_valid = [&](int tl) {
+    const int left = N - tl * kDronesPerWave;
+    return left < kDronesPerWave ? left : kDronesPerWave;
+  };
+  StageRegs<MAXM> pre;
+  if ((int)blockIdx.x < ntiles)
+    stage_load_once(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane, pre);
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d_raw = tile * kDronesPerWave + dl;
     const bool live = d_raw < N;
     const int d = live ? d_raw : N - 1;
-    const int left = N - tile * kDronesPerWave;
-    const int nvalid = left < kDronesPerWave ? left : kDronesPerWave;
+    const int nvalid = tile_valid(tile);
+    const int next = tile + gridDim.x;
 
     if (tile != (int)blockIdx.x) __syncthreads();
-    stage_inputs(wp, tt, shared_times, tile, nvalid, wpitch, tpitch, sWraw, sTraw, lane);
+    stage_store_once(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
     __syncthreads();
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
     const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
@@ -695,6 +757,15 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     }
 #pragma unroll
     for (int i = MAXM - 1; i >= 0; --i) {
+      if (i == (MAXM >= 2 ? 1 : 0)) {
+        // software pipelining across tiles: with two segments left most of this tile's registers
+        // are dead, so the next tile's inputs start their trip from HBM now.  Unconditional
+        // (clamped to the last tile) and at a static point of the unrolled loop: a conditional
+        // definition would keep `pre` live -- and spilled -- across the whole tile.
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = next < ntiles ? next : ntiles - 1;
+        stage_load_once(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
+      }
       if (i < M) {
         double u[NU];
 #pragma unroll
@@ -728,7 +799,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   }
 }
 
-constexpr int kRegMaxSeg = 12;   // n_seg <= 12 takes the register-resident variant
+constexpr int kRegMaxSeg = 10;   // n_seg <= 10 takes the register-resident variant
 
 template <int K>
 static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const double *t, int shared,
@@ -740,7 +811,10 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     const size_t in_bytes = solve_input_words(M) * sizeof(double);
     const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +
                              16 * nu * nu * (size_t)(M > 2 ? M - 2 : 0) * sizeof(double);
-    hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(ntiles), dim3(kWave), lds_bytes, ctx->stream,
+    // persistent waves (all resident at once) so that tile k+1's inputs can be prefetched during tile k
+    int grid = ctx->n_cu * (K <= 4 ? 8 : 4);
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
                        wp, t, shared, N, M, coef, dur, status, ntiles);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
