@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--no-saturated", action="store_true")
     ap.add_argument("--saturated-drones", type=int, default=1 << 20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a 1-GPU box "
+                         "(ranks then share device local_rank %% device_count)")
     return ap.parse_args()
 
 
@@ -216,16 +219,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)   # RCCL
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)   # RCCL
+        else:
+            dist.init_process_group(backend="gloo")
 
     from drone_path_planning_python_amd import Context
     from drone_path_planning_python_amd.synthetic import swarm
 
     M, order = args.segments, args.order
-    ctx = Context(device_id=local_rank, order=order, max_segments=max(M, 64))
+    ctx = Context(device_id=dev_index, order=order, max_segments=max(M, 64))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     wp, t = swarm(2, args.drones, M, shared_times=args.shared_times, rank=rank)
@@ -234,7 +241,7 @@ def main():
     wall, dev_ms = timed_steps(torch, dist, batch, ctx, args.steps, args.warmup, use_graph, world)
     assert int(batch.status.abs().sum().item()) == 0, "solve reported per-drone failures"
 
-    times = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+    times = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     wall_max, dev_ms_max = float(times[0].item()), float(times[1].item())

@@ -223,6 +223,24 @@ class Context:
             self._ck(self._lib.msnap_sample_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
                                                   float(dt), int(n_samples), int(n_axes), _ptr(pos)))
 
+    # ---- flatness evaluator (Trajectory.eval) -------------------------------------
+    def eval_flat(self, coef, dur, ts):
+        """coef [N,M,4,nc], dur [N,M], ts [S] -> out [N,S,13] = pos3 vel3 acc3 omega3 yaw."""
+        coef, pc = _host(coef, np.float64)
+        dur, pd = _host(dur, np.float64)
+        ts, pt = _host(ts, np.float64)
+        N, M = dur.shape
+        S = ts.shape[0]
+        out = np.empty((N, S, 13), dtype=np.float64)
+        with self._lock:
+            self._ck(self._lib.msnap_eval_flat(self._h, N, M, pc, pd, S, pt, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def eval_flat_device(self, n_drones, n_seg, coef, dur, n_samples, ts, out):
+        with self._lock:
+            self._ck(self._lib.msnap_eval_flat_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
+                                                     int(n_samples), _ptr(ts), _ptr(out)))
+
     # ---- collision passes --------------------------------------------------------
     def formation_collide(self, pos_rows, pos_cols, radius: float, row_offset: int = 0):
         pr, ppr = _host(pos_rows, np.float64)

@@ -352,6 +352,44 @@ int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, co
   return MSNAP_OK;
 }
 
+// ------------------------------------------------------------------ flatness evaluator
+int msnap_eval_flat_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                           int n_samples, const double *ts, double *out) {
+  if (!ctx || n_drones < 0 || n_samples < 0) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
+  if (!coef || !dur || !ts || !out) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_eval_flat(ctx, n_drones, n_seg, coef, dur, n_samples, ts, out);
+}
+
+int msnap_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                    int n_samples, const double *ts, double *out) {
+  if (!ctx || n_drones < 0 || n_samples < 0) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
+  if (!coef || !dur || !ts || !out) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = n_drones, nc = ctx->order + 1;
+  const size_t b_coef = N * n_seg * 4 * nc * 8, b_dur = N * n_seg * 8, b_ts = (size_t)n_samples * 8;
+  const size_t b_out = N * (size_t)n_samples * 13 * 8;
+  if ((rc = ensure(ctx, ctx->stage[2], b_coef))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[3], b_dur))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[1], b_ts))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[6], b_out))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[2].p, coef, b_coef, hipMemcpyHostToDevice, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[3].p, dur, b_dur, hipMemcpyHostToDevice, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, ts, b_ts, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_eval_flat(ctx, n_drones, n_seg, (const double *)ctx->stage[2].p, (const double *)ctx->stage[3].p,
+                        n_samples, (const double *)ctx->stage[1].p, (double *)ctx->stage[6].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(out, ctx->stage[6].p, b_out, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
 // ------------------------------------------------------------------ formation collide
 int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                                    const double *pos_rows, const double *pos_cols, double radius,

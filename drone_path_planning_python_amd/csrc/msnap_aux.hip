@@ -168,6 +168,108 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
 }
 
 // ------------------------------------------------------------------------------------
+// f1: Trajectory.eval / Polynomial4D.eval -- differential-flatness outputs
+// (reference src/optimizations/uav_trajectory.py:64-85 and :119-127: piece lookup with
+// '<=', derivative polynomials built as (i+1)*p[i+1], Horner with separate multiply and
+// add, thrust = acc + (0,0,9.81), body axes from yaw, omega from the jerk).
+//   out[d][s] = pos[3] vel[3] acc[3] omega[3] yaw ; NaN when t is outside [0, duration]
+// ------------------------------------------------------------------------------------
+template <int NC>
+__device__ __forceinline__ void horner_derivs(const double *__restrict__ c, double t, double &p0, double &p1,
+                                              double &p2, double &p3) {
+#pragma clang fp contract(off)
+  double d0[NC], d1[NC], d2[NC], d3[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) d0[i] = c[i];
+#pragma unroll
+  for (int i = 0; i < NC - 1; ++i) d1[i] = (double)(i + 1) * d0[i + 1];
+#pragma unroll
+  for (int i = 0; i < NC - 2; ++i) d2[i] = (double)(i + 1) * d1[i + 1];
+#pragma unroll
+  for (int i = 0; i < NC - 3; ++i) d3[i] = (double)(i + 1) * d2[i + 1];
+  p0 = p1 = p2 = p3 = 0.0;
+#pragma unroll
+  for (int i = NC - 1; i >= 0; --i) p0 = p0 * t + d0[i];
+#pragma unroll
+  for (int i = NC - 2; i >= 0; --i) p1 = p1 * t + d1[i];
+#pragma unroll
+  for (int i = NC - 3; i >= 0; --i) p2 = p2 * t + d2[i];
+#pragma unroll
+  for (int i = NC - 4; i >= 0; --i) p3 = p3 * t + d3[i];
+}
+
+template <int NC>
+__global__ void __launch_bounds__(256)
+flat_eval_kernel(const double *__restrict__ coef, const double *__restrict__ dur, const double *__restrict__ ts,
+                 int N, int M, int S, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  const size_t total = (size_t)N * S;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(idx / S);
+    const int s = (int)(idx - (size_t)d * S);
+    const double t = ts[s];
+    const double *dr = dur + (size_t)d * M;
+    double acc_t = 0.0;
+    int seg = -1;
+    for (int i = 0; i < M; ++i) {
+      const double Ti = dr[i];
+      if (seg < 0) {
+        if (t <= acc_t + Ti) seg = i;
+        else acc_t = acc_t + Ti;
+      }
+    }
+    double *o = out + idx * 13;
+    if (!(t >= 0.0) || seg < 0) {
+#pragma unroll
+      for (int q = 0; q < 13; ++q) o[q] = __builtin_nan("");
+      continue;
+    }
+    const double tl = t - acc_t;
+    const double *c = coef + ((size_t)d * M + seg) * 4 * NC;
+    double px, vx, ax, jx, py, vy, ay, jy, pz, vz, az, jz, yaw, dyaw, q2, q3;
+    horner_derivs<NC>(c + 0 * NC, tl, px, vx, ax, jx);
+    horner_derivs<NC>(c + 1 * NC, tl, py, vy, ay, jy);
+    horner_derivs<NC>(c + 2 * NC, tl, pz, vz, az, jz);
+    horner_derivs<NC>(c + 3 * NC, tl, yaw, dyaw, q2, q3);
+    const double thx = ax + 0.0, thy = ay + 0.0, thz = az + 9.81;
+    const double tn = sqrt(thx * thx + thy * thy + thz * thz);
+    const double zbx = thx / tn, zby = thy / tn, zbz = thz / tn;
+    const double xwx = cos(yaw), xwy = sin(yaw), xwz = 0.0;
+    // y_body = normalize(z_body x x_world)
+    double ybx = zby * xwz - zbz * xwy, yby = zbz * xwx - zbx * xwz, ybz = zbx * xwy - zby * xwx;
+    const double yn = sqrt(ybx * ybx + yby * yby + ybz * ybz);
+    ybx = ybx / yn; yby = yby / yn; ybz = ybz / yn;
+    // x_body = y_body x z_body
+    const double xbx = yby * zbz - ybz * zby, xby = ybz * zbx - ybx * zbz, xbz = ybx * zby - yby * zbx;
+    const double jd = jx * zbx + jy * zby + jz * zbz;
+    const double hx = (jx - jd * zbx) / tn, hy = (jy - jd * zby) / tn, hz = (jz - jd * zbz) / tn;
+    o[0] = px; o[1] = py; o[2] = pz;
+    o[3] = vx; o[4] = vy; o[5] = vz;
+    o[6] = ax; o[7] = ay; o[8] = az;
+    o[9] = -(hx * ybx + hy * yby + hz * ybz);
+    o[10] = hx * xbx + hy * xby + hz * xbz;
+    o[11] = zbz * dyaw;
+    o[12] = yaw;
+  }
+}
+
+int launch_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                     int n_samples, const double *ts, double *out) {
+  const size_t total = (size_t)n_drones * n_samples;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > (size_t)ctx->n_cu * 16) blocks = (size_t)ctx->n_cu * 16;
+  if (ctx->order == 7)
+    hipLaunchKernelGGL((flat_eval_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, ts,
+                       n_drones, n_seg, n_samples, out);
+  else
+    hipLaunchKernelGGL((flat_eval_kernel<10>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, ts,
+                       n_drones, n_seg, n_samples, out);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // Formation pass: for every owned drone i the minimum over all other drones j and
 // all common samples s of |p_i(s) - p_j(s)|.  One lane per row drone; the column
 // drone is wave-uniform, so its samples come through the scalar cache.  The

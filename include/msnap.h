@@ -139,6 +139,17 @@ int msnap_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *c
                         const double *dur, double dt, int n_samples, int n_axes,
                         double *pos);
 
+/* ---- Trajectory.eval / Polynomial4D.eval: differential-flatness outputs -------------
+ * replaces src/optimizations/uav_trajectory.py:64-85 (pos, vel, acc, omega, yaw from the
+ * x,y,z,yaw polynomials) with the piece lookup of Trajectory.eval, :119-127 ('<=').
+ *   ts  [n_samples] sample times shared by all drones
+ *   out [n_drones][n_samples][13] = pos[3] vel[3] acc[3] omega[3] yaw ; NaN outside [0, duration]
+ */
+int msnap_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                    int n_samples, const double *ts, double *out);
+int msnap_eval_flat_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                           const double *dur, int n_samples, const double *ts, double *out);
+
 /* ---- drone-vs-drone formation pass (new capability; no reference) -------
  * rows: the n_rows drones this caller owns (a shard), starting at global index
  * row_offset; cols: all n_cols drones (after the all-gather).  Spheres of `radius`.
