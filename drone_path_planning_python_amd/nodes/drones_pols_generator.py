@@ -49,6 +49,28 @@ def path_time_grid(n_poses: int, total_duration: float = TOTAL_DURATION) -> np.n
     return np.array([step * i for i in range(n_poses)], dtype=np.float64)
 
 
+def allocate_times(positions: np.ndarray, total_duration: float = TOTAL_DURATION, mode: str = "uniform") -> np.ndarray:
+    """Waypoint times for a path of m poses.
+
+    "uniform"  the reference's grid, t_i = i * total / m (reference :44-46,56);
+    "distance" SURVEY.md 8f rank 3: segment durations proportional to the Euclidean
+               length of each leg (zero-length legs get the mean share so that the times
+               stay strictly increasing), scaled so that the last waypoint keeps the
+               reference's end time total * (m-1) / m."""
+    positions = np.asarray(positions, dtype=np.float64)
+    m = positions.shape[0]
+    if mode == "uniform":
+        return path_time_grid(m, total_duration)
+    if mode != "distance":
+        raise ValueError("mode must be 'uniform' or 'distance'")
+    leg = np.linalg.norm(np.diff(positions[:, :3], axis=0), axis=1)
+    mean = leg.mean() if leg.size and leg.mean() > 0 else 1.0
+    leg = np.where(leg > 0, leg, mean)
+    end = total_duration * (m - 1) / m
+    t = np.concatenate([[0.0], np.cumsum(leg)])
+    return t * (end / t[-1])
+
+
 def paths_to_waypoints(paths: Sequence) -> tuple:
     """Path-likes with equal pose counts -> (wp [N,m,4], t [m])."""
     arrays = [msgs.path_to_arrays(p) for p in paths]

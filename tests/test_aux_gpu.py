@@ -237,3 +237,36 @@ def test_flatness_evaluator_batch_on_solved_swarm(ctx7):
             pos, vel, acc, omega, yaw = O.trajectory_eval(matd, float(ts[s]))
             ref = np.concatenate([pos, vel, acc, omega, [yaw]])
             np.testing.assert_allclose(out[d, s], ref, rtol=1e-10, atol=1e-10)
+
+
+def test_device_formation_pass_single_rank(ctx7):
+    """swarm.DeviceCompute end to end on device tensors (world = 1: no collective),
+    against the host-pointer entry points."""
+    import torch
+    from drone_path_planning_python_amd import swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(41, 70, 8)
+    wp[..., :3] *= 0.3
+    comp = sw.DeviceCompute(ctx7, torch)
+    try:
+        coef, dur, status = comp.solve(torch.from_numpy(wp).cuda(), torch.from_numpy(t).cuda())
+        assert int(status.abs().sum().item()) == 0
+        S = 40
+        res = sw.formation_pass(comp, coef, dur, 70, 1, 0, 0.1, S, 0.2, dist=None, torch=torch)
+        tris = torch.from_numpy(np.ascontiguousarray(
+            __import__("drone_path_planning_python_amd.stl", fromlist=["box_mesh"]).box_mesh((-1, -1, -1), (0, 0, 0)))).cuda()
+        mmd, mhit = comp.mesh(res.positions_all, tris, 0.2)
+        torch.cuda.synchronize()
+    finally:
+        ctx7.use_own_stream()
+    hcoef, hdur, _ = ctx7.solve_batch(wp, t)
+    np.testing.assert_array_equal(coef.cpu().numpy(), hcoef)
+    hpos = ctx7.sample(hcoef, hdur, 0.1, S, 3)
+    np.testing.assert_array_equal(res.positions_all.cpu().numpy(), hpos)
+    hmd, hpartner, hhit = ctx7.formation_collide(hpos, hpos, 0.2)
+    np.testing.assert_array_equal(res.min_dist.cpu().numpy(), hmd)
+    np.testing.assert_array_equal(res.partner.cpu().numpy(), hpartner)
+    np.testing.assert_array_equal(res.hit.cpu().numpy().astype(bool), hhit)
+    hm, hh = ctx7.mesh_sweep(hpos, tris.cpu().numpy(), 0.2)
+    np.testing.assert_array_equal(mmd.cpu().numpy(), hm)
+    assert (res.lo, res.hi) == (0, 70)

@@ -160,3 +160,15 @@ def test_oracle_formation_and_collision_semantics():
     assert O.point_triangle_dist2(np.array([0.2, 0.2, 0.5]), *tri[0]) == pytest.approx(0.25)
     assert O.point_triangle_dist2(np.array([-1.0, -1.0, 0.0]), *tri[0]) == pytest.approx(2.0)
     assert O.point_triangle_dist2(np.array([1.0, 1.0, 0.0]), *tri[0]) == pytest.approx(0.5)
+
+
+def test_allocate_times_modes():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 2, 0], [1, 2, 0], [4, 6, 0.0]])
+    tu = dpg.allocate_times(pos, 10.0, "uniform")
+    np.testing.assert_array_equal(tu, dpg.path_time_grid(5))
+    td = dpg.allocate_times(pos, 10.0, "distance")
+    assert td[0] == 0.0 and abs(td[-1] - 8.0) < 1e-12 and (np.diff(td) > 0).all()
+    legs = np.diff(td)
+    assert abs(legs[1] / legs[0] - 2.0) < 1e-12 and abs(legs[3] / legs[0] - 5.0) < 1e-12
+    with pytest.raises(ValueError):
+        dpg.allocate_times(pos, 10.0, "nope")
