@@ -2,6 +2,7 @@
 // wrappers, stream / timer plumbing.  All compute happens in the HIP kernels
 // of msnap_solve.hip / msnap_aux.hip; there is no CPU fallback.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -76,6 +77,10 @@ int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
   ctx->order = order;
   ctx->khalf = (order + 1) / 2;
   ctx->max_segments = max_segments;
+  {
+    const char *e = getenv("MSNAP_NO_TWIST");
+    ctx->no_twist = (e && e[0] == '1') ? 1 : 0;
+  }
   int rc = MSNAP_OK;
   do {
     if (hipSetDevice(device_id) != hipSuccess) { rc = MSNAP_ENODEVICE; break; }

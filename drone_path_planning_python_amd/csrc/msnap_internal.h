@@ -50,6 +50,7 @@ struct msnap_ctx {
   msnap::DevBuf grid_t, grid_wp, grid_op, grid_dur, grid_status, grid_frag;
   int grid_seg = 0;
   int grid_ready = 0;
+  int no_twist = 0;        // MSNAP_NO_TWIST=1: keep small batches on the one-sided kernels (A/B timing)
   char hip_err[256] = {0};
 };
 

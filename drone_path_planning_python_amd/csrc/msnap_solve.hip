@@ -324,10 +324,10 @@ __device__ __forceinline__ void quad_exchange(double &A, double &B, bool bit) {
   B = nb;
 }
 
-__device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_base, size_t drone_stride,
-                                                    int nvalid, int lane, const double (&c)[8], bool bad) {
-  const int a = lane & 3;
-  const int dl = lane >> 2;
+// `blk` is this lane's drone-segment block (4 axes x 8 coefficients); all 4 axis lanes of a
+// quad must take the same path (the exchanges are quad-local).
+__device__ __forceinline__ void store_quad8_at(double *__restrict__ blk, bool ok, int a, const double (&c)[8],
+                                               bool bad) {
   const double nanv = __builtin_nan("");
   double p0x = bad ? nanv : c[0], p0y = bad ? nanv : c[1], p1x = bad ? nanv : c[2], p1y = bad ? nanv : c[3];
   double p2x = bad ? nanv : c[4], p2y = bad ? nanv : c[5], p3x = bad ? nanv : c[6], p3y = bad ? nanv : c[7];
@@ -341,17 +341,22 @@ __device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_bas
   quad_exchange<0x4E>(p1x, p3x, b1);
   quad_exchange<0x4E>(p1y, p3y, b1);
   // now piece q = coefficient pair `a` of axis q
-  bool ok = dl < nvalid;
 #ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
   ok = ok && (p0x == 12345.678);
 #endif
   if (ok) {
-    double *o = seg_base + (size_t)dl * drone_stride + a * 2;
+    double *o = blk + a * 2;
     *reinterpret_cast<double2 *>(o + 0) = make_double2(p0x, p0y);
     *reinterpret_cast<double2 *>(o + 8) = make_double2(p1x, p1y);
     *reinterpret_cast<double2 *>(o + 16) = make_double2(p2x, p2y);
     *reinterpret_cast<double2 *>(o + 24) = make_double2(p3x, p3y);
   }
+}
+
+__device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_base, size_t drone_stride,
+                                                    int nvalid, int lane, const double (&c)[8], bool bad) {
+  const int dl = lane >> 2;
+  store_quad8_at(seg_base + (size_t)dl * drone_stride, dl < nvalid, lane & 3, c, bad);
 }
 
 // dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
@@ -799,6 +804,246 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   }
 }
 
+// ------------------------------------------------------------------------------------
+// small-batch variant (order 7, 3 <= n_seg <= 2*MAXH): two-sided ("twisted") sweep.
+// With few drones a launch is one wavefront's dependent chain, so the chain is halved:
+// lane = 8*drone + 4*side + axis.  Side 0 sweeps the knots from the start of the path,
+// side 1 runs THE SAME recurrence on the time-reversed path (p'(s) = p(T_total - s):
+// waypoints and segment lengths reversed, odd derivatives change sign), both stop at the
+// middle segment, exchange their last (G, z) through one cross-lane swap, solve the
+// 2-knot coupling
+//     u_a = z_a - G_a u_b ,   D u_b = z_b - G_b D u_a ,   D = diag(-1, +1, -1)
+// and back-substitute outwards.  Side 1 converts its pieces back with a Taylor shift by
+// the segment length and a sign flip of the odd coefficients (p(t) = q(T - t)).
+// ------------------------------------------------------------------------------------
+constexpr int kTwistDrones = 8;
+
+template <int MAXH>
+__global__ void __launch_bounds__(kWave)
+solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+                   int N, int M, double *__restrict__ coef, double *__restrict__ dur,
+                   int32_t *__restrict__ status, int ntiles) {
+  using SW = Sweep<4>;
+  constexpr int NU = 3, NC = 8;
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int lane = threadIdx.x;
+  const int a = lane & 3;
+  const int side = (lane >> 2) & 1;
+  const int dl = lane >> 3;           // drone inside the tile
+  const int hd = lane >> 2;           // (drone, side): 16 per wave, the G stash is per hd
+  const int wpitch = (M + 1) * 4;
+  const int tpitch = M + 1;
+  const int mL = (M - 1) / 2, mR = (M - 1) - mL;      // knots per side, mL <= mR
+  const int mside = side ? mR : mL;
+  const int mmax = mR;
+  double *sWraw = lds;
+  double *sTraw = sWraw + kTwistDrones * wpitch;
+  double *sG = sTraw + kTwistDrones * tpitch;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int d_raw = tile * kTwistDrones + dl;
+    const bool live = d_raw < N;
+    const int d = live ? d_raw : N - 1;
+    const int left = N - tile * kTwistDrones;
+    const int nvalid = left < kTwistDrones ? left : kTwistDrones;
+
+    if (tile != (int)blockIdx.x) __syncthreads();
+    {   // stage the 8 drones' inputs (one flight)
+      const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kTwistDrones * wpitch);
+      double2 *wdst = reinterpret_cast<double2 *>(sWraw);
+      const int wcnt = nvalid * wpitch / 2;
+      const double *tsrc = shared_times ? tt : tt + (size_t)tile * kTwistDrones * tpitch;
+      const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+      constexpr int UW = (2 * MAXH + 2 + 3) / 4, UT = (2 * MAXH + 2 + 7) / 8;   // 8*(M+1)*2/64, 8*(M+1)/64
+      double2 vw[UW];
+      double vt[UT];
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int e = u * kWave + lane;
+        vw[u] = wsrc[e < wcnt ? e : wcnt - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int f = u * kWave + lane;
+        vt[u] = tsrc[f < tcnt ? f : tcnt - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(vw[u].x), "+v"(vw[u].y));
+#pragma unroll
+      for (int u = 0; u < UT; ++u) asm volatile("" : "+v"(vt[u]));
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int e = u * kWave + lane;
+        if (e < wcnt) wdst[e] = vw[u];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int f = u * kWave + lane;
+        if (f < tcnt) sTraw[f] = vt[u];
+      }
+    }
+    __syncthreads();
+    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
+
+    const int dloc = live ? dl : (N - 1 - tile * kTwistDrones);
+    const double *lw = sWraw + dloc * wpitch + a;
+    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
+    // own-coordinate accessors: side 1 walks the path backwards
+    auto Wown = [&](int i) -> double { return lw[(side ? M - i : i) * 4]; };
+    auto Town = [&](int i) -> double {
+      const int j = side ? M - 1 - i : i;
+      return lt[j + 1] - lt[j];
+    };
+
+    double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[MAXH][NU];
+    double Gl[NU][NU], zl[NU];
+    const double t0 = lt[0];
+    wreg[0] = Wown(0);
+    wreg[1] = Wown(1);
+    const double T0 = Town(0);
+    Treg[0] = side ? T0 : T0 - t0;   // Appendix-A quirk lives on the start side only
+    bool nonfinite = !(finite64(t0) && finite64(T0) && finite64(wreg[0]) && finite64(wreg[1]));
+    bool badtime = !(T0 > 0.0) || !(Treg[0] > 0.0) || (t0 < 0.0);
+    xreg[0] = rcp64(Treg[0]);
+    SW sw;
+    sw.init(xreg[0], wreg[1] - wreg[0]);
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      zl[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Gl[r][c] = 0.0;
+    }
+
+#pragma unroll
+    for (int it = 1; it <= MAXH; ++it) {
+      if (it <= mmax) {            // wave-uniform
+        if (it <= mside) {         // per side
+          wreg[it + 1] = Wown(it + 1);
+          Treg[it] = Town(it);
+          nonfinite = nonfinite || !finite64(Treg[it]) || !finite64(wreg[it + 1]);
+          badtime = badtime || !(Treg[it] > 0.0);
+          xreg[it] = rcp64(Treg[it]);
+          double G[NU][NU], z[NU];
+          sw.step(xreg[it], wreg[it + 1] - wreg[it], G, z);
+          double *g = sG + (it - 1) * (NU * NU * 16) + hd;
+#pragma unroll
+          for (int r = 0; r < NU; ++r) {
+            zreg[it - 1][r] = z[r];
+            zl[r] = z[r];
+#pragma unroll
+            for (int c = 0; c < NU; ++c) {
+              g[(r * NU + c) * 16] = G[r][c];
+              Gl[r][c] = G[r][c];
+            }
+          }
+        }
+      }
+    }
+
+    // per-drone status over the 8 lanes (2 sides x 4 axes)
+    int flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (sw.singular ? 1 : 0);
+    flags |= __shfl_xor(flags, 1);
+    flags |= __shfl_xor(flags, 2);
+    flags |= __shfl_xor(flags, 4);
+    const int st = (flags & 4) ? MSNAP_ST_NONFINITE : (flags & 2) ? MSNAP_ST_TIMES : (flags & 1) ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
+    if (live && (lane & 7) == 0) status[d] = st;
+    const bool bad = st != 0;
+
+    // ---- merge: swap (G, z) of the two sides' last knots, solve the 2-knot coupling ----
+    double Go[NU][NU], zo[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      zo[r] = __shfl_xor(zl[r], 4);
+#pragma unroll
+      for (int c = 0; c < NU; ++c) Go[r][c] = __shfl_xor(Gl[r][c], 4);
+    }
+    const double dsg[NU] = {-1.0, 1.0, -1.0};
+    double A[NU][NU], rhs[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      double rv = zl[r];
+#pragma unroll
+      for (int q = 0; q < NU; ++q) rv = __builtin_fma(-Gl[r][q] * dsg[q], zo[q], rv);
+      rhs[r] = rv;
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) v = __builtin_fma(-Gl[r][q] * dsg[q], Go[q][c] * dsg[c], v);
+        A[r][c] = v;
+      }
+    }
+    // 3x3 solve by cofactors (A = S_a^-1 x Schur complement of an SPD system: well conditioned)
+    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    const double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
+    const double idet = rcp64(det);
+    const double c10 = A[0][2] * A[2][1] - A[0][1] * A[2][2];
+    const double c11 = A[0][0] * A[2][2] - A[0][2] * A[2][0];
+    const double c12 = A[0][1] * A[2][0] - A[0][0] * A[2][1];
+    const double c20 = A[0][1] * A[1][2] - A[0][2] * A[1][1];
+    const double c21 = A[0][2] * A[1][0] - A[0][0] * A[1][2];
+    const double c22 = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+    double ulast[NU], unext[NU];
+    ulast[0] = (c00 * rhs[0] + c10 * rhs[1] + c20 * rhs[2]) * idet;
+    ulast[1] = (c01 * rhs[0] + c11 * rhs[1] + c21 * rhs[2]) * idet;
+    ulast[2] = (c02 * rhs[0] + c12 * rhs[1] + c22 * rhs[2]) * idet;
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      double v = zo[r];
+#pragma unroll
+      for (int c = 0; c < NU; ++c) v = __builtin_fma(-Go[r][c] * dsg[c], ulast[c], v);
+      unext[r] = dsg[r] * v;
+    }
+
+    // ---- outward back-substitution + recovery; side 0 also owns the middle segment ----
+    const int top = side ? mside - 1 : mside;
+    double un[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) un[r] = side ? ulast[r] : unext[r];
+#pragma unroll
+    for (int it = MAXH; it >= 0; --it) {
+      if (it <= mmax) {          // wave-uniform (top <= mmax)
+        if (it <= top) {         // per side; the 4 axis lanes of a quad agree
+          double u[NU];
+          if (it >= 1) {
+            const double *g = sG + (it - 1) * (NU * NU * 16) + hd;
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+              double v = zreg[it >= 1 ? it - 1 : 0][r];
+#pragma unroll
+              for (int c = 0; c < NU; ++c) v = __builtin_fma(-g[(r * NU + c) * 16], un[c], v);
+              u[r] = (side == 0 && it == mside) ? ulast[r] : v;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < NU; ++r) u[r] = 0.0;
+          }
+          double c[NC];
+          recover_segment<4>(wreg[it], wreg[it + 1] - wreg[it], Treg[it], xreg[it], u, un, c);
+          if (side) {
+            taylor_shift<NC>(c, Treg[it]);      // q(s + T), then p(t) = q(T - t): odd powers flip
+#pragma unroll
+            for (int m = 1; m < NC; m += 2) c[m] = -c[m];
+            c[0] = wreg[it + 1];                // p(0) is the waypoint itself: keep it exact
+          } else if (it == 0 && t0 != 0.0) {
+            taylor_shift<NC>(c, -t0);
+          }
+          const int seg = side ? M - 1 - it : it;
+          store_quad8_at(coef + ((size_t)d * M + seg) * (4 * NC), live, a, c, bad);
+#pragma unroll
+          for (int r = 0; r < NU; ++r) un[r] = u[r];
+        }
+      }
+    }
+  }
+}
+
+constexpr int kTwistMaxHalf = 6;   // twisted variant: 3 <= n_seg <= 12
+
 constexpr int kRegMaxSeg = 10;   // n_seg <= 10 takes the register-resident variant
 
 template <int K>
@@ -806,6 +1051,16 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
+  if (K == 4 && M >= 3 && M <= 2 * kTwistMaxHalf && ntiles <= ctx->n_cu && !ctx->no_twist) {
+    // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
+    const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
+    const int mR = (M - 1) - (M - 1) / 2;
+    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR) * sizeof(double);
+    hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp, t,
+                       shared, N, M, coef, dur, status, nt8);
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
+  }
   if (M <= kRegMaxSeg) {
     const size_t nu = K - 1;
     const size_t in_bytes = solve_input_words(M) * sizeof(double);

@@ -318,3 +318,30 @@ def test_grid_status_and_errors():
         wp, _ = swarm(78, 10, 6, shared_times=True)
         coef, dur, status = ctx.solve_grid(wp)
         assert (status == 2).all() and np.isnan(coef).all()
+
+
+# ---------------------------------------------------------------------------
+# small-batch two-sided ("twisted") kernel vs the one-sided kernels
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("m", [3, 4, 5, 9, 10, 11, 12])
+def test_twisted_and_one_sided_kernels_agree(m, monkeypatch):
+    """Batches below one wavefront per CU take solve_kernel_twist; MSNAP_NO_TWIST=1 keeps
+    them on the one-sided kernels.  Both must match the oracle, and each other to ~1e-12."""
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(500 + m, 37, m)
+    t[5] += 0.3                     # one drone with t[0] != 0 (quirk on the start side)
+    with Context(order=7, max_segments=64) as ctx:
+        c_tw, d_tw, s_tw = ctx.solve_batch(wp, t)
+    monkeypatch.setenv("MSNAP_NO_TWIST", "1")
+    with Context(order=7, max_segments=64) as ctx:
+        c_os, d_os, s_os = ctx.solve_batch(wp, t)
+    assert (s_tw == 0).all() and (s_os == 0).all()
+    import msnap_oracle as O
+    ref, rdur = O.solve_batch_fast(wp, t)
+    assert norm_rel(c_tw, ref) <= 1e-9
+    assert norm_rel(c_os, ref) <= 1e-9
+    assert norm_rel(c_tw, c_os) <= 1e-11
+    np.testing.assert_array_equal(d_tw, rdur)
+    keep = np.arange(37) != 5                                        # drone 5 has the t[0] quirk: c0 != w_0 there
+    np.testing.assert_array_equal(c_tw[keep][..., 0], wp[keep, :-1, :])   # c0 == w_i exactly on both sides
