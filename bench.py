@@ -46,19 +46,30 @@ def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
     return n_drones * (8 * 5 * (n_seg + 1) + 8 * n_seg * (1 + 4 * (order + 1)))
 
 
-def pmc_traffic(kernel: str, n_drones: int, n_seg: int):
-    """HBM bytes per launch of `kernel` at this grid, from the committed PMC passes
-    (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X:
-    separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
-    MI355X_MICROARCH.md's gfx950 correction).  None when no matching profile exists."""
+def pmc_traffic(n_drones: int, n_seg: int, order: int):
+    """(HBM bytes per launch, kernel name) of the solve at this workload, from the committed PMC
+    passes (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X: separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
+    correction).  (None, None) when no matching profile exists."""
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(tp) as f:
             rec = json.load(f)
-        ent = rec.get(f"{kernel}|{((n_drones + 15) // 16) * 64}|M{n_seg}") or {}
-        return ent.get("hbm_bytes_per_launch")
+        ent = rec.get(f"{n_drones}x{n_seg}o{order}") or {}
+        return ent.get("hbm_bytes_per_launch"), ent.get("kernel")
     except Exception:
-        return None
+        return None, None
+
+
+def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
+    """Which K1 variant libmsnap launches (mirror of launch_solve_k in csrc/msnap_solve.hip)."""
+    k = (order + 1) // 2
+    ntiles = (n_drones + 15) // 16
+    if k == 4 and 3 <= n_seg <= 12 and ntiles <= n_cu:
+        return "msnap::solve_kernel_twist<6>"
+    if n_seg <= 10:
+        return "msnap::solve_kernel_reg<%d, 10>" % k
+    return "msnap::solve_kernel<%d, false>" % k
 
 
 def parse():
@@ -73,6 +84,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true")
+    ap.add_argument("--no-shared-grid", action="store_true")
     ap.add_argument("--saturated-drones", type=int, default=1 << 20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
@@ -264,8 +276,8 @@ def main():
             "value": nbig / per, "unit": "trajectories/s", "ms_per_launch": per * 1e3,
             "roofline": {"bound": "hbm", "achieved": b / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b / per / 1e9 / HBM_PEAK_GBS, "frac_of_copy_achievable": b / per / 1e9 / HBM_COPY_GBS,
-                         "traffic": pmc_traffic(("msnap::solve_kernel_reg<%d, 12>" if M <= 12 else
-                                                 "msnap::solve_kernel<%d, false>") % ((order + 1) // 2), nbig, M)},
+                         "kernel": solve_kernel_name(nbig, M, order),
+                         "traffic": pmc_traffic(nbig, M, order)[0]},
         }
         del big
 
@@ -273,7 +285,7 @@ def main():
     # (operator built once by msnap_grid_prepare, then one fp64 MFMA GEMM per batch).
     # Reported beside the headline, never as `value`: the factorisation is outside the step.
     grid = None
-    if rank == 0 and not args.no_saturated:
+    if rank == 0 and not args.no_shared_grid:
         wps, ts = swarm(2, args.drones, M, shared_times=True)
         ctx.prepare_grid(ts)
         gsmall = GridBatch(torch, ctx, wps, M, order, device)
@@ -306,8 +318,8 @@ def main():
         total = args.drones * world * args.steps
         per_launch_s = dev_ms_max * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes(args.drones, M, order)
-        kname = ("msnap::solve_kernel_reg<%d, 12>" if M <= 12 else "msnap::solve_kernel<%d, false>") % ((order + 1) // 2)
-        traffic = pmc_traffic(kname, args.drones, M)
+        kname = solve_kernel_name(args.drones, M, order)
+        traffic = pmc_traffic(args.drones, M, order)[0]
         line = {
             "metric": METRIC,
             "value": total / wall_max,

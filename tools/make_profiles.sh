@@ -16,15 +16,20 @@ python3 tools/prof_summary.py $OUT/trace $OUT/kernel_summary.md > /dev/null
 echo "== 2. un-profiled bench line (the number to quote)"
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 
-echo "== 3. HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)"
+echo "== 3. HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), per workload"
+HEAD="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-saturated --no-shared-grid"
+SAT="--no-graph --drones 1048576 --steps 5 --warmup 2 --no-cpu-baseline --no-saturated --no-shared-grid"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$C.err || { tail -5 $OUT/pmc_$C.err; exit 1; }
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_256x10o7_$C -- python3 bench.py $HEAD > /dev/null 2> $OUT/pmc_h_$C.err || { tail -5 $OUT/pmc_h_$C.err; exit 1; }
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_1048576x10o7_$C -- python3 bench.py $SAT > /dev/null 2> $OUT/pmc_s_$C.err || { tail -5 $OUT/pmc_s_$C.err; exit 1; }
 done
-echo "== 4. SQ counters of the solve kernel"
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq1 -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq1.err || exit 1
-rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --no-graph --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2> $OUT/pmc_sq2.err || exit 1
+echo "== 4. SQ counters (all kernels of the default command: solve variants + the K2 MFMA GEMM)"
+ALL="--no-graph --steps 100 --warmup 10 --no-cpu-baseline"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_all_sq1 -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_sq1.err || exit 1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_all_sq2 -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_sq2.err || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr --kernel-trace --output-format csv -d $OUT/pmc_all_mem -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_mem.err || exit 1
 python3 tools/pmc_summary.py $OUT > $OUT/pmc_summary.md
-cat $OUT/pmc_summary.md
+cat $OUT/pmc_summary.md | tail -25
 # keep the merged-back payload small
-rm -rf $OUT/trace $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_sq1 $OUT/pmc_sq2
-tail -c 1500 $OUT/bench.json
+rm -rf $OUT/trace $OUT/pmc_*_FETCH_SIZE $OUT/pmc_*_WRITE_SIZE $OUT/pmc_all_sq1 $OUT/pmc_all_sq2 $OUT/pmc_all_mem
+tail -c 1200 $OUT/bench.json
