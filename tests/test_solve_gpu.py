@@ -345,3 +345,50 @@ def test_twisted_and_one_sided_kernels_agree(m, monkeypatch):
     np.testing.assert_array_equal(d_tw, rdur)
     keep = np.arange(37) != 5                                        # drone 5 has the t[0] quirk: c0 != w_0 there
     np.testing.assert_array_equal(c_tw[keep][..., 0], wp[keep, :-1, :])   # c0 == w_i exactly on both sides
+
+
+# ---------------------------------------------------------------------------
+# robustness: wide ranges of segment lengths and coordinates (no pivoting, rcp + Newton)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scale_t,scale_w", [(1e-3, 1.0), (1.0, 1e6), (50.0, 1e-4), (1e-2, 1e3)])
+def test_extreme_scales(ctx7, scale_t, scale_w):
+    """Very short / long segments and large / tiny coordinates: the solve is scale-covariant,
+    c_k(scaled) = c_k * scale_w / scale_t^k, so the check is independent of the oracle's own
+    conditioning (the dense LU degrades long before the block LDL^T does)."""
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(600, 24, 10)
+    base, dur0, st0 = ctx7.solve_batch(wp, t)
+    coef, dur, st = ctx7.solve_batch(wp * scale_w, t * scale_t)
+    assert (st0 == 0).all() and (st == 0).all()
+    k = np.arange(8)
+    # compare in the units of the base problem (the raw coefficients span 20+ decades)
+    assert norm_rel(coef * scale_t ** k / scale_w, base) <= 1e-9
+    np.testing.assert_allclose(dur, dur0 * scale_t, rtol=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_uneven_segment_lengths(ctx7, seed):
+    """Segment lengths spanning 1:200 inside one path (the case where an unpivoted, unscaled
+    factorisation would be at risk), against the extended-precision reference solve."""
+    rng = np.random.default_rng(700 + seed)
+    N, M = 6, 8
+    wp = rng.uniform(-5, 5, size=(N, M + 1, 4))
+    T = 10.0 ** rng.uniform(-1.3, 1.0, size=(N, M))
+    t = np.concatenate([np.zeros((N, 1)), np.cumsum(T, axis=1)], axis=1)
+    coef, dur, status = ctx7.solve_batch(wp, t)
+    assert (status == 0).all()
+    import msnap_oracle as O
+    for d in range(N):
+        for a in range(4):
+            A, b = O.assemble_1d(t[d], wp[d, :, a])
+            x = np.linalg.solve(A.astype(np.longdouble).astype(np.float64), b)
+            # iterative refinement in long double pins the reference solution itself
+            Al, bl = A.astype(np.longdouble), b.astype(np.longdouble)
+            xl = x.astype(np.longdouble)
+            for _ in range(4):
+                r = bl - Al @ xl
+                xl = xl + np.linalg.solve(A, r.astype(np.float64)).astype(np.longdouble)
+            ref = xl.astype(np.float64).reshape(M, 8)
+            num = np.abs(coef[d, :, a, :] - ref).max()
+            # observed worst case 1.5e-8 (1:200 length ratios); the gate is the north-star's 1e-6
+            assert num / np.abs(ref).max() <= 1e-6, (d, a, num / np.abs(ref).max())
