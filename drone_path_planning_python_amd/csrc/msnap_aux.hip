@@ -294,7 +294,10 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
   double best = INFINITY;
   int bestj = -1;
   const double *pr = prow + (size_t)r * S * 3;
-  for (int s0 = 0; s0 < S; s0 += kSampleChunk) {
+  for (int sc = 0; sc < S; sc += kSampleChunk) {
+    // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
+    // seeing a sample twice), so every chunk of a path with S >= 8 takes the wide-load path
+    const int s0 = (S - sc < kSampleChunk && S >= kSampleChunk) ? S - kSampleChunk : sc;
     const int ns = (S - s0 < kSampleChunk) ? (S - s0) : kSampleChunk;
     double rx[kSampleChunk], ry[kSampleChunk], rz[kSampleChunk];
 #pragma unroll
@@ -304,22 +307,47 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
       ry[q] = pr[(size_t)sq * 3 + 1];
       rz[q] = pr[(size_t)sq * 3 + 2];
     }
-    for (int j = c0; j < c1; ++j) {
-      const double *pc = pcol + (size_t)j * S * 3;
-      double m = INFINITY;
+    if (ns == kSampleChunk) {
+      // full chunk: the column drone's 8 samples are 24 contiguous doubles at a wave-uniform
+      // address -> three wide scalar loads issued together, one wait, then 8 x 7 VALU ops
+      for (int j = c0; j < c1; ++j) {
+        const double *pc = pcol + ((size_t)j * S + s0) * 3;
+        double cb[3 * kSampleChunk];
 #pragma unroll
-      for (int q = 0; q < kSampleChunk; ++q) {
-        const int sq = (q < ns) ? (s0 + q) : s0;
-        const double dx = pc[(size_t)sq * 3 + 0] - rx[q];
-        const double dy = pc[(size_t)sq * 3 + 1] - ry[q];
-        const double dz = pc[(size_t)sq * 3 + 2] - rz[q];
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        m = (d2 < m) ? d2 : m;
+        for (int q = 0; q < 3 * kSampleChunk; ++q) cb[q] = pc[q];
+        double m = INFINITY;
+#pragma unroll
+        for (int q = 0; q < kSampleChunk; ++q) {
+          const double dx = cb[3 * q + 0] - rx[q];
+          const double dy = cb[3 * q + 1] - ry[q];
+          const double dz = cb[3 * q + 2] - rz[q];
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          m = __builtin_fmin(d2, m);
+        }
+        if (j == grow) m = INFINITY;
+        if (m < best || (m == best && j < bestj)) {
+          best = m;
+          bestj = j;
+        }
       }
-      if (j == grow) m = INFINITY;
-      if (m < best || (m == best && j < bestj)) {
-        best = m;
-        bestj = j;
+    } else {
+      for (int j = c0; j < c1; ++j) {
+        const double *pc = pcol + (size_t)j * S * 3;
+        double m = INFINITY;
+#pragma unroll
+        for (int q = 0; q < kSampleChunk; ++q) {
+          const int sq = (q < ns) ? (s0 + q) : s0;
+          const double dx = pc[(size_t)sq * 3 + 0] - rx[q];
+          const double dy = pc[(size_t)sq * 3 + 1] - ry[q];
+          const double dz = pc[(size_t)sq * 3 + 2] - rz[q];
+          const double d2 = dx * dx + dy * dy + dz * dz;
+          m = (d2 < m) ? d2 : m;
+        }
+        if (j == grow) m = INFINITY;
+        if (m < best || (m == best && j < bestj)) {
+          best = m;
+          bestj = j;
+        }
       }
     }
   }

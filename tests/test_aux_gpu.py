@@ -270,3 +270,18 @@ def test_device_formation_pass_single_rank(ctx7):
     hm, hh = ctx7.mesh_sweep(hpos, tris.cpu().numpy(), 0.2)
     np.testing.assert_array_equal(mmd.cpu().numpy(), hm)
     assert (res.lo, res.hi) == (0, 70)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/msnap.h consumed by a C99 program compiled with gcc (no C++, no Python in the
+    loop): configs[0] solved on the GPU against the reference's known-answer vector."""
+    import subprocess
+    from conftest import ROOT
+    from drone_path_planning_python_amd import _lib
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-o", exe, "-L", libdir, "-lmsnap", "-lm",
+                    "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "max abs err" in out and "dur 1.0 2.0 1.0" in out
