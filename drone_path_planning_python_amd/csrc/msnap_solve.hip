@@ -734,7 +734,12 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         badtime = badtime || !(Treg[i] > 0.0);
         xreg[i] = rcp64(Treg[i]);
         double G[NU][NU], z[NU];
+#ifdef MSNAP_EXPERIMENT_STORE_ONLY
+#pragma unroll
+        for (int r = 0; r < NU; ++r) { z[r] = xreg[i]; for (int c = 0; c < NU; ++c) G[r][c] = wreg[i]; }
+#else
         sw.step(xreg[i], wreg[i + 1] - wreg[i], G, z);
+#endif
         if (i < M - 1) {
           double *g = sG + (i - 1) * (NU * NU * 16) + dl;
 #pragma unroll
@@ -790,9 +795,18 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
             for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
         }
         double c[NC];
+#ifdef MSNAP_EXPERIMENT_STORE_ONLY
+#pragma unroll
+        for (int m = 0; m < NC; ++m) c[m] = u[m % NU] + wreg[i];
+#else
         recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], Treg[i], xreg[i], u, un, c);
+#endif
         if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+#ifdef MSNAP_EXPERIMENT_LDS_TR
+        if constexpr (false)
+#else
         if constexpr (NC == 8)
+#endif
           store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
         else
           store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
