@@ -1036,18 +1036,31 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 #pragma unroll
             for (int r = 0; r < NU; ++r) u[r] = 0.0;
           }
-          double c[NC];
-          recover_segment<4>(wreg[it], wreg[it + 1] - wreg[it], Treg[it], xreg[it], u, un, c);
-          if (side) {
-            taylor_shift<NC>(c, Treg[it]);      // q(s + T), then p(t) = q(T - t): odd powers flip
+          // Side 1 holds the piece in reversed time, q(s) with p(t) = q(T - t).  Its endpoint states in
+          // forward time are the reversed ones with the odd derivatives negated, so the forward
+          // coefficients come from the same recovery with the two ends swapped -- no Taylor shift.
+          double ua[NU], ub[NU];
 #pragma unroll
-            for (int m = 1; m < NC; m += 2) c[m] = -c[m];
-            c[0] = wreg[it + 1];                // p(0) is the waypoint itself: keep it exact
-          } else if (it == 0 && t0 != 0.0) {
-            taylor_shift<NC>(c, -t0);
+          for (int r = 0; r < NU; ++r) {
+            ua[r] = side ? dsg[r] * un[r] : u[r];      // state at the forward start of the piece
+            ub[r] = side ? dsg[r] * u[r] : un[r];      // state at its forward end
           }
+          const double wa = side ? wreg[it + 1] : wreg[it];
+          const double wb = side ? wreg[it] : wreg[it + 1];
+          double c[NC];
+          recover_segment<4>(wa, wb - wa, Treg[it], xreg[it], ua, ub, c);
+          if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
           const int seg = side ? M - 1 - it : it;
-          store_quad8_at(coef + ((size_t)d * M + seg) * (4 * NC), live, a, c, bad);
+          // a batch this small is latency bound, not store bound: plain per-lane stores
+          if (bad) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
+          }
+          if (live) {
+            double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
+#pragma unroll
+            for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
+          }
 #pragma unroll
           for (int r = 0; r < NU; ++r) un[r] = u[r];
         }
