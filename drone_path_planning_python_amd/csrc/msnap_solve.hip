@@ -1069,7 +1069,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   }
 }
 
-constexpr int kTwistMaxHalf = 6;   // twisted variant: 3 <= n_seg <= 12
+constexpr int kTwistMaxHalf = 6;    // twisted variant: 3 <= n_seg <= 12 ...
+constexpr int kTwistMaxHalf2 = 12;  // ... and 13 <= n_seg <= 24 (one wave per SIMD: > 256 VGPRs)
 
 constexpr int kRegMaxSeg = 10;   // n_seg <= 10 takes the register-resident variant
 
@@ -1078,13 +1079,17 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
-  if (K == 4 && M >= 3 && M <= 2 * kTwistMaxHalf && ntiles <= ctx->n_cu && !ctx->no_twist) {
+  if (K == 4 && M >= 3 && M <= 2 * kTwistMaxHalf2 && ntiles <= ctx->n_cu && !ctx->no_twist) {
     // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int mR = (M - 1) - (M - 1) / 2;
     const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR) * sizeof(double);
-    hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp, t,
-                       shared, N, M, coef, dur, status, nt8);
+    if (M <= 2 * kTwistMaxHalf)
+      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp,
+                         t, shared, N, M, coef, dur, status, nt8);
+    else
+      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf2>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp,
+                         t, shared, N, M, coef, dur, status, nt8);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
