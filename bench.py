@@ -180,6 +180,16 @@ def timed_steps(torch, dist, batch, ctx, steps, warmup, use_graph, world):
     return wall, dev_ms
 
 
+def python_restatement_rate(wp, t, order, n=24):
+    """Calibration only: the NumPy restatement that follows the reference step for step
+    (oracle/msnap_oracle.py, dense assembly + np.linalg.solve per axis, bit-identical to the
+    reference), single core -- the reference itself measures ~100 trajectories/s."""
+    import msnap_oracle
+    t0 = time.perf_counter()
+    msnap_oracle.solve_batch(wp[:n], t[:n], ncoef=order + 1)
+    return n / (time.perf_counter() - t0)
+
+
 def cpu_baseline(n_seg, order, seconds):
     """C restatement of the reference algorithm (oracle/msnap_oracle.c, one dense
     LU with partial pivoting per axis like calculate_trajectory4D) on the host
@@ -217,6 +227,7 @@ def cpu_baseline(n_seg, order, seconds):
                   f"(C restatement of the reference algorithm), OpenMP over drones, {dt:.1f} s",
         "single_thread_value": n1 / dt1,
         "host_cpus": os.cpu_count(),
+        "python_restatement_single_core": python_restatement_rate(wp, t, order),
     }
 
 
