@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-pointer entry point msnap_solve_batch (H2D + kernel + D2H,
+pageable NumPy buffers) -- quoted in DESIGN.md 7, never bench.py's `value`."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drone_path_planning_python_amd import Context  # noqa: E402
+from drone_path_planning_python_amd.synthetic import swarm  # noqa: E402
+
+out = []
+with Context(0, 7, 64) as ctx:
+    for n in (1, 256, 4096, 65536, 1 << 20):
+        wp, t = swarm(2, n, 10)
+        ctx.solve_batch(wp, t)
+        reps = 200 if n <= 4096 else (20 if n <= 65536 else 3)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.solve_batch(wp, t)
+        dt = (time.perf_counter() - t0) / reps
+        out.append({"drones": n, "ms_per_call": dt * 1e3, "traj_per_s": n / dt,
+                    "GBps_moved": n * 3080 / dt / 1e9})
+print(json.dumps(out))
