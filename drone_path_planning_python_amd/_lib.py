@@ -48,6 +48,8 @@ SIGNATURES = {
     "msnap_sample_device": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _I, _VP]),
     "msnap_eval_flat": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP]),
     "msnap_eval_flat_device": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP]),
+    "msnap_snap_cost": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
+    "msnap_snap_cost_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_formation_collide": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_collide_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_mesh_sweep": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),

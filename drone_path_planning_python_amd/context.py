@@ -241,6 +241,22 @@ class Context:
             self._ck(self._lib.msnap_eval_flat_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
                                                      int(n_samples), _ptr(ts), _ptr(out)))
 
+    # ---- snap cost ---------------------------------------------------------------------
+    def snap_cost(self, coef, dur):
+        """J = sum_seg int (p^(k))^2 dt per drone and axis -> [N, 4]."""
+        coef, pc = _host(coef, np.float64)
+        dur, pd = _host(dur, np.float64)
+        N, M = dur.shape
+        cost = np.empty((N, 4), dtype=np.float64)
+        with self._lock:
+            self._ck(self._lib.msnap_snap_cost(self._h, N, M, pc, pd, cost.ctypes.data_as(ctypes.c_void_p)))
+        return cost
+
+    def snap_cost_device(self, n_drones, n_seg, coef, dur, cost):
+        with self._lock:
+            self._ck(self._lib.msnap_snap_cost_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
+                                                     _ptr(cost)))
+
     # ---- collision passes --------------------------------------------------------
     def formation_collide(self, pos_rows, pos_cols, radius: float, row_offset: int = 0):
         pr, ppr = _host(pos_rows, np.float64)

@@ -395,6 +395,40 @@ int msnap_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
   return MSNAP_OK;
 }
 
+// ------------------------------------------------------------------ snap cost
+int msnap_snap_cost_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                           double *cost) {
+  if (!ctx || n_drones < 0) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!coef || !dur || !cost) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_snap_cost(ctx, n_drones, n_seg, coef, dur, cost);
+}
+
+int msnap_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double *cost) {
+  if (!ctx || n_drones < 0) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!coef || !dur || !cost) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = n_drones, nc = ctx->order + 1;
+  const size_t b_coef = N * n_seg * 4 * nc * 8, b_dur = N * n_seg * 8, b_cost = N * 4 * 8;
+  if ((rc = ensure(ctx, ctx->stage[2], b_coef))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[3], b_dur))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[6], b_cost))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[2].p, coef, b_coef, hipMemcpyHostToDevice, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[3].p, dur, b_dur, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_snap_cost(ctx, n_drones, n_seg, (const double *)ctx->stage[2].p, (const double *)ctx->stage[3].p,
+                        (double *)ctx->stage[6].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(cost, ctx->stage[6].p, b_cost, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
 // ------------------------------------------------------------------ formation collide
 int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                                    const double *pos_rows, const double *pos_cols, double radius,

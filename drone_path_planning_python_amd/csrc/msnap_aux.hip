@@ -270,6 +270,59 @@ int launch_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 }
 
 // ------------------------------------------------------------------------------------
+// Snap cost J = sum_seg int_0^T (p^(k)(t))^2 dt per (drone, axis), k = (order+1)/2: the quantity
+// the trajectory minimises (the reference never evaluates it; it is the objective of the QP
+// whose KKT system its collocation rows encode).  Monomial Hessian
+//   Q[m][n] = m!/(m-k)! * n!/(n-k)! * T^(m+n-2k+1) / (m+n-2k+1),  m, n >= k.
+// ------------------------------------------------------------------------------------
+template <int NC>
+__global__ void __launch_bounds__(256)
+snap_cost_kernel(const double *__restrict__ coef, const double *__restrict__ dur, int N, int M,
+                 double *__restrict__ cost) {
+  constexpr int K = NC / 2;
+  const int total = N * 4;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int d = idx >> 2, a = idx & 3;
+    double J = 0.0;
+    for (int i = 0; i < M; ++i) {
+      const double *c = coef + (((size_t)d * M + i) * 4 + a) * NC;
+      const double T = dur[(size_t)d * M + i];
+      double f[K];                      // f[q] = (k+q)!/q! * c[k+q]
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        double ff = 1.0;
+#pragma unroll
+        for (int r = q + 1; r <= K + q; ++r) ff *= (double)r;
+        f[q] = ff * c[K + q];
+      }
+      double tp[2 * K];                 // T^e, e = 1 .. 2k-1
+      tp[0] = 1.0;
+#pragma unroll
+      for (int e = 1; e < 2 * K; ++e) tp[e] = tp[e - 1] * T;
+      double acc = 0.0;
+#pragma unroll
+      for (int p = 0; p < K; ++p)
+#pragma unroll
+        for (int q = 0; q < K; ++q) acc += f[p] * f[q] * (tp[p + q + 1] / (double)(p + q + 1));
+      J += acc;
+    }
+    cost[idx] = J;
+  }
+}
+
+int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double *cost) {
+  const int total = n_drones * 4;
+  int blocks = (total + 255) / 256;
+  if (blocks > ctx->n_cu * 8) blocks = ctx->n_cu * 8;
+  if (ctx->order == 7)
+    hipLaunchKernelGGL((snap_cost_kernel<8>), dim3(blocks), dim3(256), 0, ctx->stream, coef, dur, n_drones, n_seg, cost);
+  else
+    hipLaunchKernelGGL((snap_cost_kernel<10>), dim3(blocks), dim3(256), 0, ctx->stream, coef, dur, n_drones, n_seg, cost);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // Formation pass: for every owned drone i the minimum over all other drones j and
 // all common samples s of |p_i(s) - p_j(s)|.  One lane per row drone; the column
 // drone is wave-uniform, so its samples come through the scalar cache.  The

@@ -76,6 +76,7 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
                   double dt, int n_samples, int n_axes, double *pos);
 int launch_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
                      int n_samples, const double *ts, double *out);
+int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double *cost);
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                              const double *pos_rows, const double *pos_cols, double radius,
                              double *min_dist, int32_t *partner, int32_t *hit);

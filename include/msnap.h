@@ -150,6 +150,16 @@ int msnap_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
 int msnap_eval_flat_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
                            const double *dur, int n_samples, const double *ts, double *out);
 
+/* ---- snap cost J = sum_seg int (p^(k))^2 dt per drone and axis (k = 4 at order 7) ------
+ * The objective whose KKT system the reference's collocation rows encode
+ * (src/optimizations/calculatingTrajectories.py:13-33 states the conditions; the
+ * reference never evaluates J).   cost [n_drones][4]
+ */
+int msnap_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                    double *cost);
+int msnap_snap_cost_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                           const double *dur, double *cost);
+
 /* ---- drone-vs-drone formation pass (new capability; no reference) -------
  * rows: the n_rows drones this caller owns (a shard), starting at global index
  * row_offset; cols: all n_cols drones (after the all-gather).  Spheres of `radius`.

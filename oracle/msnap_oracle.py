@@ -410,6 +410,23 @@ def trajectory_eval(matrix: np.ndarray, t: float):
     return None
 
 
+def snap_cost(coef: np.ndarray, dur: np.ndarray) -> np.ndarray:
+    """J = sum_seg int_0^T (p^(k))^2 dt per axis, k = ncoef/2, by exact integration of the
+    squared k-th derivative polynomial.  coef [M,4,ncoef], dur [M] -> [4].  (The reference
+    never evaluates its objective; the conditions it solves are the stationarity conditions
+    of this functional -- calculatingTrajectories.py:13-33.)"""
+    M, _, nc = coef.shape
+    k = nc // 2
+    out = np.zeros(4)
+    for a in range(4):
+        for i in range(M):
+            p = np.polynomial.Polynomial(coef[i, a])
+            q = p.deriv(k)
+            sq = (q * q).integ()
+            out[a] += sq(dur[i]) - sq(0.0)
+    return out
+
+
 # --------------------------------------------------------------------------
 # Collision passes -- NEW capability, no reference implementation: PARITY
 # UNPINNED (SURVEY.md 8c).  Semantics defined by this repo (DESIGN.md):
