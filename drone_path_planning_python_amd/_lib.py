@@ -54,6 +54,8 @@ SIGNATURES = {
     "msnap_formation_collide_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_mesh_sweep": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
     "msnap_mesh_sweep_device": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
+    "msnap_mesh_validity": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP]),
+    "msnap_mesh_validity_device": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP]),
 }
 
 

@@ -295,6 +295,26 @@ class Context:
                                                hit.ctypes.data_as(ctypes.c_void_p)))
         return md, hit.astype(bool)
 
+    def mesh_validity(self, states, robot_tris, env_tris):
+        """states [N,4] (x,y,z,yaw), meshes [R,3,3] / [E,3,3] -> valid [N] bool (True = no collision):
+        the planner's isStateValid for a batch of states."""
+        st, pst = _host(states, np.float64)
+        rt, prt = _host(robot_tris, np.float64)
+        et, pet = _host(env_tris, np.float64)
+        if st.ndim != 2 or st.shape[1] != 4:
+            raise ValueError("states must be [N, 4]")
+        N = st.shape[0]
+        valid = np.empty((N,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_mesh_validity(self._h, N, pst, rt.shape[0], prt, et.shape[0], pet,
+                                                  valid.ctypes.data_as(ctypes.c_void_p)))
+        return valid.astype(bool)
+
+    def mesh_validity_device(self, n_states, states, n_rtris, rtris, n_etris, etris, valid):
+        with self._lock:
+            self._ck(self._lib.msnap_mesh_validity_device(self._h, int(n_states), _ptr(states), int(n_rtris),
+                                                         _ptr(rtris), int(n_etris), _ptr(etris), _ptr(valid)))
+
     def mesh_sweep_device(self, n_drones, n_samples, pos, n_tris, tris, radius, min_dist, hit):
         with self._lock:
             self._ck(self._lib.msnap_mesh_sweep_device(self._h, int(n_drones), int(n_samples), _ptr(pos),

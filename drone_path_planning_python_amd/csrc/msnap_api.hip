@@ -505,4 +505,37 @@ int msnap_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *
   return MSNAP_OK;
 }
 
+// ------------------------------------------------------------------ mesh-vs-mesh validity
+int msnap_mesh_validity_device(msnap_ctx *ctx, int n_states, const double *states, int n_rtris, const double *rtris,
+                               int n_etris, const double *etris, int32_t *valid) {
+  if (!ctx || n_states < 0 || n_rtris < 0 || n_etris < 0) return MSNAP_EINVAL;
+  if (n_states == 0) return MSNAP_OK;
+  if (!states || !valid || (n_rtris > 0 && !rtris) || (n_etris > 0 && !etris)) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_mesh_validity(ctx, n_states, states, n_rtris, rtris, n_etris, etris, valid);
+}
+
+int msnap_mesh_validity(msnap_ctx *ctx, int n_states, const double *states, int n_rtris, const double *rtris,
+                        int n_etris, const double *etris, int32_t *valid) {
+  if (!ctx || n_states < 0 || n_rtris < 0 || n_etris < 0) return MSNAP_EINVAL;
+  if (n_states == 0) return MSNAP_OK;
+  if (!states || !valid || (n_rtris > 0 && !rtris) || (n_etris > 0 && !etris)) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_st = (size_t)n_states * 4 * 8, b_r = (size_t)n_rtris * 9 * 8, b_e = (size_t)n_etris * 9 * 8;
+  int rc;
+  if ((rc = ensure(ctx, ctx->stage[0], b_st))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[1], b_r + 8))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[2], b_e + 8))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[4], (size_t)n_states * 4))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, states, b_st, hipMemcpyHostToDevice, ctx->stream));
+  if (b_r) MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, rtris, b_r, hipMemcpyHostToDevice, ctx->stream));
+  if (b_e) MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[2].p, etris, b_e, hipMemcpyHostToDevice, ctx->stream));
+  rc = launch_mesh_validity(ctx, n_states, (const double *)ctx->stage[0].p, n_rtris, (const double *)ctx->stage[1].p,
+                            n_etris, (const double *)ctx->stage[2].p, (int32_t *)ctx->stage[4].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(valid, ctx->stage[4].p, (size_t)n_states * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
 }  // extern "C"

@@ -553,4 +553,107 @@ int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double 
   return MSNAP_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// f4: rigid-body state validity, batched -- the OMPL validity callback of the planner
+// (reference src/RigidBodyPlanners/RB_planning_sep_coll_check.py:208-226: the robot mesh
+// is placed at (x, y, z) with quaternion_from_euler(0, 0, yaw) and fcl.collide is asked
+// whether it touches the environment mesh, src/RigidBodyPlanners/fcl_checker.py:93-100).
+// FCL is not vendored in the reference (parity unpinned): the predicate here is "some
+// robot triangle and some environment triangle intersect as closed sets", decided by the
+// 17-axis separating-axis test (2 face normals, 9 edge x edge, 6 edge x normal for the
+// coplanar case).  One wavefront per state, lanes stride the triangle pairs.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sat_separates(const double (&P)[3][3], const double (&Q)[3][3], double lx, double ly,
+                                              double lz) {
+#pragma clang fp contract(off)
+  double p0 = P[0][0] * lx + P[0][1] * ly + P[0][2] * lz;
+  double p1 = P[1][0] * lx + P[1][1] * ly + P[1][2] * lz;
+  double p2 = P[2][0] * lx + P[2][1] * ly + P[2][2] * lz;
+  double q0 = Q[0][0] * lx + Q[0][1] * ly + Q[0][2] * lz;
+  double q1 = Q[1][0] * lx + Q[1][1] * ly + Q[1][2] * lz;
+  double q2 = Q[2][0] * lx + Q[2][1] * ly + Q[2][2] * lz;
+  const double pmin = fmin(p0, fmin(p1, p2)), pmax = fmax(p0, fmax(p1, p2));
+  const double qmin = fmin(q0, fmin(q1, q2)), qmax = fmax(q0, fmax(q1, q2));
+  return (pmin > qmax) || (pmax < qmin);
+}
+
+__device__ __forceinline__ bool tri_tri_intersect(const double (&P)[3][3], const double (&Q)[3][3]) {
+#pragma clang fp contract(off)
+  double e[3][3], f[3][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    e[0][c] = P[1][c] - P[0][c]; e[1][c] = P[2][c] - P[1][c]; e[2][c] = P[0][c] - P[2][c];
+    f[0][c] = Q[1][c] - Q[0][c]; f[1][c] = Q[2][c] - Q[1][c]; f[2][c] = Q[0][c] - Q[2][c];
+  }
+  const double n1x = e[0][1] * e[1][2] - e[0][2] * e[1][1];
+  const double n1y = e[0][2] * e[1][0] - e[0][0] * e[1][2];
+  const double n1z = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+  if (sat_separates(P, Q, n1x, n1y, n1z)) return false;
+  const double n2x = f[0][1] * f[1][2] - f[0][2] * f[1][1];
+  const double n2y = f[0][2] * f[1][0] - f[0][0] * f[1][2];
+  const double n2z = f[0][0] * f[1][1] - f[0][1] * f[1][0];
+  if (sat_separates(P, Q, n2x, n2y, n2z)) return false;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double lx = e[i][1] * f[j][2] - e[i][2] * f[j][1];
+      const double ly = e[i][2] * f[j][0] - e[i][0] * f[j][2];
+      const double lz = e[i][0] * f[j][1] - e[i][1] * f[j][0];
+      if (sat_separates(P, Q, lx, ly, lz)) return false;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double lx = n1y * e[i][2] - n1z * e[i][1], ly = n1z * e[i][0] - n1x * e[i][2], lz = n1x * e[i][1] - n1y * e[i][0];
+    if (sat_separates(P, Q, lx, ly, lz)) return false;
+    lx = n2y * f[i][2] - n2z * f[i][1]; ly = n2z * f[i][0] - n2x * f[i][2]; lz = n2x * f[i][1] - n2y * f[i][0];
+    if (sat_separates(P, Q, lx, ly, lz)) return false;
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(kWave)
+mesh_validity_kernel(const double *__restrict__ states, int N, const double *__restrict__ rtris, int R,
+                     const double *__restrict__ etris, int E, int32_t *__restrict__ valid) {
+#pragma clang fp contract(off)
+  const int sidx = blockIdx.x;
+  const int lane = threadIdx.x;
+  const double tx = states[(size_t)sidx * 4 + 0], ty = states[(size_t)sidx * 4 + 1], tz = states[(size_t)sidx * 4 + 2];
+  const double yaw = states[(size_t)sidx * 4 + 3];
+  // quaternion_from_euler(0, 0, yaw) = (0, 0, sin(yaw/2), cos(yaw/2)); its rotation matrix
+  const double qz = sin(0.5 * yaw), qw = cos(0.5 * yaw);
+  const double c = 1.0 - 2.0 * (qz * qz), s2 = 2.0 * (qz * qw);
+  bool hit = false;
+  const int pairs = R * E;
+  for (int p0 = 0; p0 < pairs; p0 += kWave) {
+    const int p = p0 + lane;
+    if (p < pairs) {
+      const int rt = p / E, et = p - rt * E;
+      double P[3][3], Q[3][3];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {
+        const double x = rtris[(size_t)rt * 9 + v * 3 + 0], y = rtris[(size_t)rt * 9 + v * 3 + 1];
+        P[v][0] = (c * x - s2 * y) + tx;
+        P[v][1] = (s2 * x + c * y) + ty;
+        P[v][2] = rtris[(size_t)rt * 9 + v * 3 + 2] + tz;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Q[v][k] = etris[(size_t)et * 9 + v * 3 + k];
+      }
+      hit = hit || tri_tri_intersect(P, Q);
+    }
+    if (__ballot(hit) != 0ULL) break;   // wave-uniform early exit
+  }
+  const unsigned long long any = __ballot(hit);
+  if (lane == 0) valid[sidx] = (any == 0ULL) ? 1 : 0;
+}
+
+int launch_mesh_validity(msnap_ctx *ctx, int n_states, const double *states, int n_rtris, const double *rtris,
+                         int n_etris, const double *etris, int32_t *valid) {
+  hipLaunchKernelGGL(mesh_validity_kernel, dim3(n_states), dim3(kWave), 0, ctx->stream, states, n_states, rtris,
+                     n_rtris, etris, n_etris, valid);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
 }  // namespace msnap

@@ -82,6 +82,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                              double *min_dist, int32_t *partner, int32_t *hit);
 int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
                       const double *tris, double radius, double *min_dist, int32_t *hit);
+int launch_mesh_validity(msnap_ctx *ctx, int n_states, const double *states, int n_rtris, const double *rtris,
+                         int n_etris, const double *etris, int32_t *valid);
 int solve_kernel_setup(msnap_ctx *ctx);
 int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device);
 int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,

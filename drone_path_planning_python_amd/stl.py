@@ -23,6 +23,12 @@ def load_stl(path: str) -> np.ndarray:
     return np.ascontiguousarray(body["v"].astype(np.float64))
 
 
+def load_stl_planner(path: str) -> np.ndarray:
+    """As the planner's Fcl_mesh.load_stl sees the file: vertices rounded to 2 decimals
+    (src/RigidBodyPlanners/fcl_checker.py:19-25, np.around(env_mesh.vectors, 2))."""
+    return np.around(load_stl(path), 2)
+
+
 def save_stl(path: str, tris: np.ndarray) -> None:
     """Write float vertices [n,3,3] as binary STL (normals recomputed, attribute 0)."""
     tris = np.asarray(tris, dtype=np.float64)

@@ -189,6 +189,20 @@ int msnap_mesh_sweep_device(msnap_ctx *ctx, int n_drones, int n_samples, const d
                             int n_tris, const double *tris, double radius,
                             double *min_dist, int32_t *hit);
 
+/* ---- rigid-body state validity, batched (the planner's OMPL validity callback) -------
+ * replaces isStateValid, src/RigidBodyPlanners/RB_planning_sep_coll_check.py:208-226
+ * (robot mesh at (x,y,z) with quaternion_from_euler(0,0,yaw), fcl.collide against the
+ * environment mesh, src/RigidBodyPlanners/fcl_checker.py:93-100) for many states at once.
+ *   states [n_states][4]  x, y, z, yaw
+ *   rtris  [n_rtris][3][3] robot mesh (body frame), etris [n_etris][3][3] environment mesh
+ *   valid  [n_states]  1 = no robot triangle intersects an environment triangle
+ */
+int msnap_mesh_validity(msnap_ctx *ctx, int n_states, const double *states, int n_rtris,
+                        const double *rtris, int n_etris, const double *etris, int32_t *valid);
+int msnap_mesh_validity_device(msnap_ctx *ctx, int n_states, const double *states, int n_rtris,
+                               const double *rtris, int n_etris, const double *etris,
+                               int32_t *valid);
+
 #ifdef __cplusplus
 }
 #endif

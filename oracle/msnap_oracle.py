@@ -513,3 +513,62 @@ def load_stl_binary(path: str) -> np.ndarray:
     rec = np.dtype([('n', '<f4', 3), ('v', '<f4', (3, 3)), ('attr', '<u2')])
     body = np.frombuffer(raw, dtype=rec, count=n, offset=84)
     return body['v'].astype(np.float64)
+
+
+# --------------------------------------------------------------------------
+# f4: batched isStateValid (RB_planning_sep_coll_check.py:208-226, fcl_checker.py:93-100).
+# python-fcl is not vendored: PARITY UNPINNED.  Predicate: closed triangles intersect,
+# by the 17-axis separating-axis test; same operation order as the kernel.
+# --------------------------------------------------------------------------
+def _separates(P, Q, L):
+    p = [P[v][0] * L[0] + P[v][1] * L[1] + P[v][2] * L[2] for v in range(3)]
+    q = [Q[v][0] * L[0] + Q[v][1] * L[1] + Q[v][2] * L[2] for v in range(3)]
+    return min(p) > max(q) or max(p) < min(q)
+
+
+def _cross(a, b):
+    return (a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0])
+
+
+def tri_tri_intersect(P, Q) -> bool:
+    e = [[P[1][c] - P[0][c] for c in range(3)], [P[2][c] - P[1][c] for c in range(3)],
+         [P[0][c] - P[2][c] for c in range(3)]]
+    f = [[Q[1][c] - Q[0][c] for c in range(3)], [Q[2][c] - Q[1][c] for c in range(3)],
+         [Q[0][c] - Q[2][c] for c in range(3)]]
+    n1 = _cross(e[0], e[1])
+    if _separates(P, Q, n1):
+        return False
+    n2 = _cross(f[0], f[1])
+    if _separates(P, Q, n2):
+        return False
+    for i in range(3):
+        for j in range(3):
+            if _separates(P, Q, _cross(e[i], f[j])):
+                return False
+    for i in range(3):
+        if _separates(P, Q, _cross(n1, e[i])):
+            return False
+        if _separates(P, Q, _cross(n2, f[i])):
+            return False
+    return True
+
+
+def mesh_validity(states: np.ndarray, robot_tris: np.ndarray, env_tris: np.ndarray) -> np.ndarray:
+    """states [N,4] (x,y,z,yaw) -> valid [N] bool (True = no collision)."""
+    out = np.empty(states.shape[0], dtype=bool)
+    R = np.asarray(robot_tris, dtype=np.float64).tolist()
+    E = np.asarray(env_tris, dtype=np.float64).tolist()
+    for n, (tx, ty, tz, yaw) in enumerate(np.asarray(states, dtype=np.float64).tolist()):
+        qz, qw = math.sin(0.5 * yaw), math.cos(0.5 * yaw)
+        c, s2 = 1.0 - 2.0 * (qz * qz), 2.0 * (qz * qw)
+        hit = False
+        for tri in R:
+            P = [[(c * v[0] - s2 * v[1]) + tx, (s2 * v[0] + c * v[1]) + ty, v[2] + tz] for v in tri]
+            for Q in E:
+                if tri_tri_intersect(P, Q):
+                    hit = True
+                    break
+            if hit:
+                break
+        out[n] = not hit
+    return out

@@ -325,3 +325,48 @@ def test_snap_cost_and_optimality(ctx7, golden):
                 pert[i, a] = np.linalg.solve(A, np.concatenate([states[i], states[i + 1]]))
         Jp = O.snap_cost(pert, dur[d])
         assert (Jp >= J[d] * (1 - 1e-9)).all() and (Jp > J[d]).any()
+
+
+@pytest.mark.parametrize("env_name,robot_name,lo,hi", [
+    ("env-scene-ltu-experiment.stl", "custom_triangle_robot.stl", (-3, 2.5, -0.5), (3, 5.5, 2.5)),
+    ("env-scene-hole.stl", "robot-scene-triangle.stl", (-5, -3, -3), (5, 3, 3)),
+])
+def test_mesh_validity_batch(ctx7, env_name, robot_name, lo, hi):
+    """Batched isStateValid (RB_planning_sep_coll_check.py:208-226) on the reference's own STL
+    scenes (vertices rounded to 2 dp as fcl_checker.py:19-25 does), against the oracle's
+    separating-axis predicate; FCL itself is absent, so the predicate's parity is unpinned."""
+    from drone_path_planning_python_amd import stl
+    env = stl.load_stl_planner(os.path.join(GOLDEN_DIR, env_name))
+    rob = stl.load_stl_planner(os.path.join(GOLDEN_DIR, robot_name))
+    rng = np.random.default_rng(11)
+    n = 300
+    states = np.column_stack([rng.uniform(lo[0], hi[0], n), rng.uniform(lo[1], hi[1], n),
+                              rng.uniform(lo[2], hi[2], n), rng.uniform(-np.pi, np.pi, n)])
+    got = ctx7.mesh_validity(states, rob, env)
+    ref = O.mesh_validity(states, rob, env)
+    np.testing.assert_array_equal(got, ref)
+    assert ref.any() and not ref.all()
+
+
+def test_mesh_validity_reference_start_goal(ctx7):
+    """The live configuration of scripts/rigidBodyPath.py:139-147: start (0,3,1) and goal (0,5,1)
+    on either side of the wall at y in [3.9, 4.1] are valid, a pose inside the wall is not."""
+    from drone_path_planning_python_amd import stl
+    env = stl.load_stl_planner(os.path.join(GOLDEN_DIR, "env-scene-ltu-experiment.stl"))
+    rob = stl.load_stl_planner(os.path.join(GOLDEN_DIR, "custom_triangle_robot.stl"))
+    states = np.array([[0, 3, 1, 0], [0, 5, 1, 0], [0, 4, 1, 0.3], [0, 4, 2.5, 0.0], [0, 3.6, 1.0, np.pi / 2]])
+    np.testing.assert_array_equal(ctx7.mesh_validity(states, rob, env), [True, True, False, True, False])
+    assert ctx7.mesh_validity(np.zeros((0, 4)), rob, env).shape == (0,)
+
+
+def test_mesh_sweep_on_reference_obstacle(ctx7):
+    """Drone-vs-mesh sweep against the reference's obstacle file (resources/stl, copied as data)."""
+    from drone_path_planning_python_amd import stl
+    tris = stl.load_stl(os.path.join(GOLDEN_DIR, "env-scene-hole.stl"))
+    assert tris.shape == (56, 3, 3)
+    rng = np.random.default_rng(12)
+    pos = rng.uniform([-5, -1.5, -3], [5, 1.5, 3], size=(24, 15, 3))
+    md, hit = ctx7.mesh_sweep(pos, tris, 0.15)
+    rmd, rhit = O.mesh_sweep(pos, tris, 0.15)
+    np.testing.assert_allclose(md, rmd, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(hit, rhit)
