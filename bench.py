@@ -65,10 +65,10 @@ def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) ->
     """Which K1 variant libmsnap launches (mirror of launch_solve_k in csrc/msnap_solve.hip)."""
     k = (order + 1) // 2
     ntiles = (n_drones + 15) // 16
-    if k == 4 and 3 <= n_seg <= 12 and ntiles <= n_cu:
-        return "msnap::solve_kernel_twist<6>"
-    if n_seg <= 10:
-        return "msnap::solve_kernel_reg<%d, 10>" % k
+    if k == 4 and 3 <= n_seg <= 24 and ntiles <= n_cu:
+        return "msnap::solve_kernel_twist<%d>" % (6 if n_seg <= 12 else 12)
+    if n_seg <= 20:
+        return "msnap::solve_kernel_reg<%d, %d>" % (k, 10 if n_seg <= 10 else 20)
     return "msnap::solve_kernel<%d, false>" % k
 
 

@@ -655,7 +655,7 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
 // LDS per wave = inputs + 1/T + G  (18.7 KB at n_seg = 10, order 7) -> 8 waves / CU.
 // ------------------------------------------------------------------------------------
 template <int K, int MAXM>
-__global__ void __launch_bounds__(kWave, (K <= 4 ? 2 : 1))   // order 9 needs > 256 VGPRs to stay spill-free
+__global__ void __launch_bounds__(kWave, ((K <= 4 && MAXM <= 10) ? 2 : 1))   // order 9 / 20 segments need > 256 VGPRs
 solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
                  int N, int M, double *__restrict__ coef, double *__restrict__ dur,
                  int32_t *__restrict__ status, int ntiles) {
@@ -1072,7 +1072,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxHalf = 6;    // twisted variant: 3 <= n_seg <= 12 ...
 constexpr int kTwistMaxHalf2 = 12;  // ... and 13 <= n_seg <= 24 (one wave per SIMD: > 256 VGPRs)
 
-constexpr int kRegMaxSeg = 10;   // n_seg <= 10 takes the register-resident variant
+constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
+constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
 template <int K>
 static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const double *t, int shared,
@@ -1093,16 +1094,21 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
-  if (M <= kRegMaxSeg) {
+  if (M <= kRegMaxSeg2) {
     const size_t nu = K - 1;
     const size_t in_bytes = solve_input_words(M) * sizeof(double);
     const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +
                              16 * nu * nu * (size_t)(M > 2 ? M - 2 : 0) * sizeof(double);
     // persistent waves (all resident at once) so that tile k+1's inputs can be prefetched during tile k
-    int grid = ctx->n_cu * (K <= 4 ? 8 : 4);
+    const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg);
+    int grid = ctx->n_cu * (two_per_simd ? 8 : 4);
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
-                       wp, t, shared, N, M, coef, dur, status, ntiles);
+    if (M <= kRegMaxSeg)
+      hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
+                         wp, t, shared, N, M, coef, dur, status, ntiles);
+    else
+      hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg2>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
+                         wp, t, shared, N, M, coef, dur, status, ntiles);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
