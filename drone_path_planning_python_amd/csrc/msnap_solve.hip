@@ -22,11 +22,15 @@
 // (S_i, G_i) depends on the time grid only and is recomputed by the 4 axis
 // lanes of a drone (no cross-lane traffic, no divergence: every lane runs the
 // same M-step recurrence).  The tile's inputs are staged in LDS by one
-// coalesced sweep.  Three variants share the arithmetic:
-//   solve_kernel_reg<K, MAXM>  n_seg <= MAXM: z_i in registers (loops unrolled),
-//                              G_i in LDS -> 8 waves / CU              (fast path)
-//   solve_kernel<K, false>     any n_seg that fits 160 KiB: G_i and z_i in LDS
-//   solve_kernel<K, true>      longer paths: G_i, z_i on a global scratch slab
+// coalesced sweep.  The variants share the arithmetic (Sweep<K>::step, recover_segment)
+// and are chosen per launch by launch_solve_k:
+//   solve_kernel_twist<6|12>   order 7, 3 <= n_seg <= 24, batch below one wavefront per CU:
+//                              two-sided sweep, halves the dependent chain   (latency path)
+//   solve_kernel_reg<K,10|20>  n_seg <= 20: knot loops unrolled, path data and z_i in
+//                              registers, G_i in LDS, persistent waves with cross-tile
+//                              input prefetch                               (throughput path)
+//   solve_kernel<K, false>     any n_seg whose stash fits 160 KiB: rolled loops, LDS stash
+//   solve_kernel<K, true>      longer paths: stash on a global scratch slab
 #include "msnap_consts.h"
 #include "msnap_internal.h"
 
@@ -641,8 +645,11 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
       double c[NC];
       recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
       if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-      store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
-                                  lane, c, bad);
+      if constexpr (NC == 8)
+        store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
+      else
+        store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
+                                    lane, c, bad);
 #pragma unroll
       for (int r = 0; r < NU; ++r) un[r] = u[r];
       wn = wi;
