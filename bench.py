@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--no-shared-grid", action="store_true")
     ap.add_argument("--saturated-drones", type=int, default=1 << 20)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--force-pg", action="store_true", help="initialise the process group even for one rank (rehearsal)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a 1-GPU box "
                          "(ranks then share device local_rank %% device_count)")
@@ -146,7 +147,8 @@ def timed_steps(torch, dist, batch, ctx, steps, warmup, use_graph, world):
             batch.step()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: a process-group watchdog thread polling its events must not abort the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             # inside the context the current stream is torch's capture stream
             ctx.set_stream(torch.cuda.current_stream().cuda_stream)
             for _ in range(steps):
@@ -245,7 +247,8 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    use_pg = world > 1 or (args.force_pg and "RANK" in os.environ)
+    if use_pg:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)   # RCCL
         else:
@@ -265,7 +268,7 @@ def main():
     assert int(batch.status.abs().sum().item()) == 0, "solve reported per-drone failures"
 
     times = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if use_pg:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     wall_max, dev_ms_max = float(times[0].item()), float(times[1].item())
 
@@ -323,7 +326,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(M, order, args.cpu_seconds)
 
-    if world > 1:
+    if use_pg:
         dist.barrier()
     if rank == 0:
         total = args.drones * world * args.steps
@@ -367,7 +370,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
