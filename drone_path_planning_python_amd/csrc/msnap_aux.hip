@@ -329,7 +329,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // column range is sliced over blockIdx.y; a second tiny kernel merges slices.
 // Semantics are this repo's: no reference implementation exists.
 // ------------------------------------------------------------------------------------
-constexpr int kSampleChunk = 8;
+constexpr int kSampleChunk = 6;
 
 __global__ void __launch_bounds__(kWave)
 collide_partial_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int row_offset,
@@ -362,12 +362,16 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
     }
     if (ns == kSampleChunk) {
       // full chunk: the column drone's 8 samples are 24 contiguous doubles at a wave-uniform
-      // address -> three wide scalar loads issued together, one wait, then 8 x 7 VALU ops
-      for (int j = c0; j < c1; ++j) {
-        const double *pc = pcol + ((size_t)j * S + s0) * 3;
-        double cb[3 * kSampleChunk];
+      // address -> three wide scalar loads.  Scalar loads only have an all-or-nothing wait, so
+      // the loop is unrolled by two with two register sets: the loads of column j+1 are issued
+      // right after the wait for column j and fly during its 8 x 7 VALU operations.
+      auto fetch = [&](int j, double (&cb)[3 * kSampleChunk]) {
+        const int jc = j < c1 ? j : c1 - 1;
+        const double *pc = pcol + ((size_t)jc * S + s0) * 3;
 #pragma unroll
         for (int q = 0; q < 3 * kSampleChunk; ++q) cb[q] = pc[q];
+      };
+      auto consume = [&](int j, const double (&cb)[3 * kSampleChunk]) {
         double m = INFINITY;
 #pragma unroll
         for (int q = 0; q < kSampleChunk; ++q) {
@@ -377,11 +381,19 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
           const double d2 = dx * dx + dy * dy + dz * dz;
           m = __builtin_fmin(d2, m);
         }
-        if (j == grow) m = INFINITY;
+        if (j == grow || j >= c1) m = INFINITY;
         if (m < best || (m == best && j < bestj)) {
           best = m;
           bestj = j;
         }
+      };
+      double ca[3 * kSampleChunk], cb2[3 * kSampleChunk];
+      fetch(c0, ca);
+      for (int j = c0; j < c1; j += 2) {
+        fetch(j + 1, cb2);
+        consume(j, ca);
+        fetch(j + 2, ca);
+        consume(j + 1, cb2);
       }
     } else {
       for (int j = c0; j < c1; ++j) {
