@@ -172,3 +172,25 @@ def test_allocate_times_modes():
     assert abs(legs[1] / legs[0] - 2.0) < 1e-12 and abs(legs[3] / legs[0] - 5.0) < 1e-12
     with pytest.raises(ValueError):
         dpg.allocate_times(pos, 10.0, "nope")
+
+
+def test_bench_accounting_helpers():
+    """bench.py's roofline arithmetic: SURVEY.md 8d bytes per trajectory and the kernel-name mirror."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes(1, 10, 7) == 3080
+    assert bench.algorithmic_bytes(1, 20, 7) == 6120
+    assert bench.algorithmic_bytes(1, 10, 9) == 3720
+    assert bench.algorithmic_bytes(256, 10, 7) == 788480
+    assert bench.solve_kernel_name(256, 10, 7) == "msnap::solve_kernel_twist<6>"
+    assert bench.solve_kernel_name(4096, 20, 7) == "msnap::solve_kernel_twist<12>"
+    assert bench.solve_kernel_name(1 << 20, 10, 7) == "msnap::solve_kernel_reg<4, 10>"
+    assert bench.solve_kernel_name(1 << 20, 20, 7) == "msnap::solve_kernel_reg<4, 20>"
+    assert bench.solve_kernel_name(65536, 10, 9) == "msnap::solve_kernel_reg<5, 10>"
+    assert bench.solve_kernel_name(64, 49, 7) == "msnap::solve_kernel<4, false>"
+    assert bench.METRIC.startswith("minimum-snap trajectories/sec")
+    tr, kn = bench.pmc_traffic(256, 10, 7)
+    assert tr is None or tr > 788480 * 0.9
