@@ -370,3 +370,13 @@ def test_mesh_sweep_on_reference_obstacle(ctx7):
     rmd, rhit = O.mesh_sweep(pos, tris, 0.15)
     np.testing.assert_allclose(md, rmd, rtol=0, atol=1e-9)
     np.testing.assert_array_equal(hit, rhit)
+
+
+@pytest.mark.parametrize("script", ["01_single_trajectory.py", "02_swarm_batch.py", "03_formation_collision.py"])
+def test_examples_run(script):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], check=True, capture_output=True,
+                         text=True, timeout=300).stdout
+    assert len(out.splitlines()) >= 3
