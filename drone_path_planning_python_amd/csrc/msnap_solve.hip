@@ -70,7 +70,7 @@ struct Sweep {
   using C = HermiteConsts<K>;
 
   double E[NS], re[NU];                       // end side of the previous segment
-  double Op[NU][NU], Gp[NU][NU], zp[NU];      // O_{i-1}, G_{i-1}, z_{i-1}
+  double OtG[NS], Otz[NU];                    // O_{i-1}^T G_{i-1} (symmetric) and O_{i-1}^T z_{i-1}
   bool singular;
 
   __device__ __forceinline__ static void powers(double x, double (&xp)[PM + 1]) {
@@ -96,14 +96,9 @@ struct Sweep {
     end_side(xp, dw);
     singular = false;
 #pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      zp[r] = 0.0;
+    for (int r = 0; r < NU; ++r) Otz[r] = 0.0;
 #pragma unroll
-      for (int c = 0; c < NU; ++c) {
-        Op[r][c] = 0.0;
-        Gp[r][c] = 0.0;
-      }
-    }
+    for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
   }
 
   // knot i with segment i (x = 1/T_i, dw = w_{i+1} - w_i) on its right:
@@ -117,15 +112,10 @@ struct Sweep {
     for (int n = 1; n <= NU; ++n) {
 #pragma unroll
       for (int m = 1; m <= n; ++m) {
-        double v = __builtin_fma(C::HSS[n][m], xp[KK - n - m], E[sidx(n - 1, m - 1)]);
-#pragma unroll
-        for (int q = 0; q < NU; ++q) v = __builtin_fma(-Op[q][n - 1], Gp[q][m - 1], v);
-        S[sidx(n - 1, m - 1)] = v;
+        const double v = __builtin_fma(C::HSS[n][m], xp[KK - n - m], E[sidx(n - 1, m - 1)]);
+        S[sidx(n - 1, m - 1)] = v - OtG[sidx(n - 1, m - 1)];
       }
-      double rv = -__builtin_fma(C::HSE[n][0] * xp[KK - n], dw, re[n - 1]);
-#pragma unroll
-      for (int q = 0; q < NU; ++q) rv = __builtin_fma(-Op[q][n - 1], zp[q], rv);
-      y[n - 1] = rv;
+      y[n - 1] = -__builtin_fma(C::HSE[n][0] * xp[KK - n], dw, re[n - 1]) - Otz[n - 1];
     }
 
     // LDL^T of S; S's strict lower part holds w_rp = L_rp d_p until scaled
@@ -179,15 +169,21 @@ struct Sweep {
       }
     }
 
-    end_side(xp, dw);   // carry: end side of segment i feeds knot i+1
+    // carry to knot i+1: the end side of segment i and the Schur terms O_i^T G_i, O_i^T z_i
+    end_side(xp, dw);
 #pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      zp[r] = z[r];
+    for (int n = 0; n < NU; ++n) {
 #pragma unroll
-      for (int c = 0; c < NU; ++c) {
-        Op[r][c] = O[r][c];
-        Gp[r][c] = G[r][c];
+      for (int m = 0; m <= n; ++m) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) v = __builtin_fma(O[q][n], G[q][m], v);
+        OtG[sidx(n, m)] = v;
       }
+      double w = 0.0;
+#pragma unroll
+      for (int q = 0; q < NU; ++q) w = __builtin_fma(O[q][n], z[q], w);
+      Otz[n] = w;
     }
   }
 };
