@@ -125,7 +125,7 @@ struct Sweep {
       double dj = S[sidx(j, j)];
 #pragma unroll
       for (int p = 0; p < j; ++p) dj = __builtin_fma(-S[sidx(j, p)] * dinv[p], S[sidx(j, p)], dj);
-      singular = singular || !(dj > 0.0) || !finite64(dj);
+      singular |= !(dj > 0.0) | !finite64(dj);   // bitwise: no short-circuit branches
       dinv[j] = rcp64(dj);
 #pragma unroll
       for (int r = j + 1; r < NU; ++r) {
@@ -473,6 +473,87 @@ __device__ __forceinline__ void stage_store_once(int shared_times, int nvalid, i
   }
 }
 
+// Hand-managed variant of the same prefetch for the persistent kernel.  hipcc waits for a
+// prefetched load with vmcnt(0) once the wait sits behind the loop back-edge, which also
+// drains the tile's 40 KB of output stores at every tile boundary.  The loads are therefore
+// issued from inline asm (invisible to the compiler's wait-count pass) and retired with an
+// exact s_waitcnt vmcnt(N), N = the store instructions issued after them, so the previous
+// tile's stores stay in flight while the next tile starts.  (cdna_hip_programming.md 5.7:
+// loads inside asm are counted and waited for by hand; the wait carries the registers as
+// "+v" operands so no consumer can be scheduled above it.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int MAXM>
+struct StageRegsAsm {
+  static constexpr int UW = (MAXM + 2) / 2;
+  static constexpr int UT = (MAXM + 4) / 4;
+  u32x4 vw[UW];
+  double vt[UT];
+};
+
+template <int MAXM>
+__device__ __forceinline__ void stage_load_asm(const double *__restrict__ wp, const double *__restrict__ tt,
+                                               int shared_times, int tile, int nvalid, int wpitch, int tpitch,
+                                               int lane, StageRegsAsm<MAXM> &r) {
+  const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kDronesPerWave * wpitch);
+  const int wcnt = nvalid * wpitch / 2;
+  const double *tsrc = shared_times ? tt : tt + (size_t)tile * kDronesPerWave * tpitch;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UW; ++u) {
+    const int e = u * kWave + lane;
+    const double2 *p = wsrc + (e < wcnt ? e : wcnt - 1);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.vw[u]) : "v"(p) : "memory");
+  }
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UT; ++u) {
+    const int f = u * kWave + lane;
+    const double *p = tsrc + (f < tcnt ? f : tcnt - 1);
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.vt[u]) : "v"(p) : "memory");
+  }
+}
+
+// retire the prefetch: all but the `younger` most recent vector-memory operations are complete
+template <int MAXM>
+__device__ __forceinline__ void stage_wait_asm(StageRegsAsm<MAXM> &r, int younger) {
+  // the immediate must be a constant: the possible store counts are 0 (first tile), 4/8 (order 7,
+  // one or two segments after the prefetch) and 5/10 (order 9)
+  if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (younger == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (younger == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // tie the registers to this point so that no use is scheduled above the wait
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UW; ++u) asm volatile("" : "+v"(r.vw[u]));
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UT; ++u) asm volatile("" : "+v"(r.vt[u]));
+}
+
+template <int MAXM>
+__device__ __forceinline__ void stage_store_asm(int shared_times, int nvalid, int wpitch, int tpitch,
+                                                double *sWraw, double *sTraw, int lane, StageRegsAsm<MAXM> &r) {
+  u32x4 *wdst = reinterpret_cast<u32x4 *>(sWraw);
+  const int wcnt = nvalid * wpitch / 2;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UW; ++u) {
+    const int e = u * kWave + lane;
+    if (e < wcnt) wdst[e] = r.vw[u];
+  }
+#pragma unroll
+  for (int u = 0; u < StageRegsAsm<MAXM>::UT; ++u) {
+    const int f = u * kWave + lane;
+    if (f < tcnt) sTraw[f] = r.vt[u];
+  }
+}
+
+// one-wave workgroups: LDS is in-order within the wave, only the compiler must be held back
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
 // ------------------------------------------------------------------------------------
 // generic variant: rolled loops, G_i / z_i stashed in LDS (GS = false) or on a
 // global slab (GS = true)
@@ -538,10 +619,10 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
     double tcur = Tv(1);
     const double w0 = Wv(0);
     double wcur = Wv(1);
-    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(w0) && finite64(wcur));
+    bool nonfinite = !(finite64(t0) & finite64(tcur) & finite64(w0) & finite64(wcur));
     double T = tcur - t0;
     const double Teff = T - t0;   // Appendix-A quirk, see taylor_shift()
-    bool badtime = !(T > 0.0) || !(Teff > 0.0) || (t0 < 0.0);
+    bool badtime = !(T > 0.0) | !(Teff > 0.0) | (t0 < 0.0);
     if constexpr (GS) {
       if (live && a == 0) drow[0] = T;
     }
@@ -562,9 +643,9 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
         tpre = Tv(ip);
         wpre = Wv(ip);
       }
-      nonfinite = nonfinite || !finite64(tnext) || !finite64(wnext);
+      nonfinite |= !finite64(tnext) | !finite64(wnext);
       T = tnext - tcur;
-      badtime = badtime || !(T > 0.0);
+      badtime |= !(T > 0.0);
       if constexpr (GS) {
         if (live && a == 0) drow[i] = T;
       }
@@ -685,9 +766,11 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     const int left = N - tl * kDronesPerWave;
     return left < kDronesPerWave ? left : kDronesPerWave;
   };
-  StageRegs<MAXM> pre;
+  StageRegsAsm<MAXM> pre;
   if ((int)blockIdx.x < ntiles)
-    stage_load_once(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane, pre);
+    stage_load_asm(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane, pre);
+  // output-store instructions a tile issues after its prefetch (segments 1 and 0, or 0 alone)
+  const int stores_after_prefetch = (NC == 8 ? 4 : NC / 2) * (M >= 2 ? 2 : 1);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d_raw = tile * kDronesPerWave + dl;
@@ -696,9 +779,10 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     const int nvalid = tile_valid(tile);
     const int next = tile + gridDim.x;
 
-    if (tile != (int)blockIdx.x) __syncthreads();
-    stage_store_once(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
-    __syncthreads();
+    wave_lds_fence();   // the previous tile's LDS reads are done (in-order LDS, one wave)
+    stage_wait_asm(pre, tile == (int)blockIdx.x ? 0 : stores_after_prefetch);
+    stage_store_asm(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
+    wave_lds_fence();
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
     const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
     const double *lw = sWraw + dloc * wpitch + a;
@@ -712,10 +796,10 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     double tcur = lt[1];
     wreg[0] = lw[0];
     wreg[1] = lw[4];
-    bool nonfinite = !(finite64(t0) && finite64(tcur) && finite64(wreg[0]) && finite64(wreg[1]));
+    bool nonfinite = !(finite64(t0) & finite64(tcur) & finite64(wreg[0]) & finite64(wreg[1]));
     const double T0 = tcur - t0;
     Treg[0] = T0 - t0;            // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
-    bool badtime = !(T0 > 0.0) || !(Treg[0] > 0.0) || (t0 < 0.0);
+    bool badtime = !(T0 > 0.0) | !(Treg[0] > 0.0) | (t0 < 0.0);
     xreg[0] = rcp64(Treg[0]);
     SW sw;
     sw.init(xreg[0], wreg[1] - wreg[0]);
@@ -732,9 +816,9 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
           tpre = lt[ip];
           wpre = lw[ip * 4];
         }
-        nonfinite = nonfinite || !finite64(tnext) || !finite64(wreg[i + 1]);
+        nonfinite |= !finite64(tnext) | !finite64(wreg[i + 1]);
         Treg[i] = tnext - tcur;
-        badtime = badtime || !(Treg[i] > 0.0);
+        badtime |= !(Treg[i] > 0.0);
         xreg[i] = rcp64(Treg[i]);
         double G[NU][NU], z[NU];
 #ifdef MSNAP_EXPERIMENT_STORE_ONLY
@@ -777,7 +861,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         // definition would keep `pre` live -- and spilled -- across the whole tile.
         __builtin_amdgcn_sched_barrier(0);
         const int nx = next < ntiles ? next : ntiles - 1;
-        stage_load_once(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
+        stage_load_asm(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
       }
       if (i < M) {
         double u[NU];
@@ -921,8 +1005,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     wreg[1] = Wown(1);
     const double T0 = Town(0);
     Treg[0] = side ? T0 : T0 - t0;   // Appendix-A quirk lives on the start side only
-    bool nonfinite = !(finite64(t0) && finite64(T0) && finite64(wreg[0]) && finite64(wreg[1]));
-    bool badtime = !(T0 > 0.0) || !(Treg[0] > 0.0) || (t0 < 0.0);
+    bool nonfinite = !(finite64(t0) & finite64(T0) & finite64(wreg[0]) & finite64(wreg[1]));
+    bool badtime = !(T0 > 0.0) | !(Treg[0] > 0.0) | (t0 < 0.0);
     xreg[0] = rcp64(Treg[0]);
     SW sw;
     sw.init(xreg[0], wreg[1] - wreg[0]);
@@ -939,8 +1023,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
         if (it <= mside) {         // per side
           wreg[it + 1] = Wown(it + 1);
           Treg[it] = Town(it);
-          nonfinite = nonfinite || !finite64(Treg[it]) || !finite64(wreg[it + 1]);
-          badtime = badtime || !(Treg[it] > 0.0);
+          nonfinite |= !finite64(Treg[it]) | !finite64(wreg[it + 1]);
+          badtime |= !(Treg[it] > 0.0);
           xreg[it] = rcp64(Treg[it]);
           double G[NU][NU], z[NU];
           sw.step(xreg[it], wreg[it + 1] - wreg[it], G, z);
