@@ -7,7 +7,7 @@
 Importing the package does not touch the GPU; creating a Context loads
 csrc/libmsnap.so (raises if it is missing -- there is no CPU fallback).
 """
-from .context import Context, default_context, STATUS_TEXT  # noqa: F401
+from .context import Context, default_context, pinned_empty, STATUS_TEXT  # noqa: F401
 from ._lib import MsnapError, LIB_PATH  # noqa: F401
 
 __version__ = "0.1.0"

@@ -37,6 +37,48 @@ def _host(a, dtype):
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
+class _PinnedBlock:
+    """Owner of one msnap_host_alloc block; arrays made by pinned_empty keep it alive."""
+
+    def __init__(self, nbytes):
+        self._lib = _lib.load()
+        p = ctypes.c_void_p()
+        _lib.check(self._lib, None, self._lib.msnap_host_alloc(ctypes.byref(p), max(int(nbytes), 1)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            self._lib.msnap_host_free(ctypes.c_void_p(ptr))
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """Uninitialised NumPy array in page-locked host memory (msnap_host_alloc).  Passing such
+    arrays to solve_batch / solve_grid (inputs and `out=`) lets the copy engines move them
+    directly, overlapped with the kernel; the memory is released with the last view."""
+    dtype = np.dtype(dtype)
+    shape = (shape,) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    block = _PinnedBlock(nbytes)
+    buf = (ctypes.c_char * max(nbytes, 1)).from_address(block.ptr)
+    buf._msnap_owner = block          # the ctypes buffer is the array's base and holds the block
+    return np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+
+
+def _out_arrays(out, shapes):
+    """Validate caller-provided (coef, dur, status) or allocate them."""
+    dtypes = (np.float64, np.float64, np.int32)
+    if out is None:
+        return tuple(np.empty(s, dtype=d) for s, d in zip(shapes, dtypes))
+    if len(out) != 3:
+        raise ValueError("out must be (coef, dur, status)")
+    for a, s, d in zip(out, shapes, dtypes):
+        if not isinstance(a, np.ndarray) or a.shape != tuple(s) or a.dtype != d or not a.flags.c_contiguous \
+                or not a.flags.writeable:
+            raise ValueError(f"out arrays must be writable C-contiguous {np.dtype(d).name} of shape {tuple(s)}")
+    return tuple(out)
+
+
 class Context:
     """One msnap context (include/msnap.h: msnap_create / msnap_destroy)."""
 
@@ -100,9 +142,10 @@ class Context:
         return float(ms.value)
 
     # ---- a1/a2 solve ----------------------------------------------------------
-    def solve_batch(self, wp, t):
+    def solve_batch(self, wp, t, out=None):
         """wp [N, m, 4], t [N, m] or shared [m] (host) ->
-        coef [N, M, 4, ncoef], dur [N, M], status [N] int32."""
+        coef [N, M, 4, ncoef], dur [N, M], status [N] int32.
+        `out=(coef, dur, status)` writes into caller-owned arrays (e.g. from pinned_empty)."""
         wp, pwp = _host(wp, np.float64)
         t, pt = _host(t, np.float64)
         if wp.ndim != 3 or wp.shape[2] != 4:
@@ -112,9 +155,7 @@ class Context:
         if (shared and t.shape != (m,)) or (not shared and t.shape != (N, m)):
             raise ValueError("t must be [N, m] or [m]")
         M = m - 1
-        coef = np.empty((N, max(M, 0), 4, self.ncoef), dtype=np.float64)
-        dur = np.empty((N, max(M, 0)), dtype=np.float64)
-        status = np.empty((N,), dtype=np.int32)
+        coef, dur, status = _out_arrays(out, ((N, max(M, 0), 4, self.ncoef), (N, max(M, 0)), (N,)))
         with self._lock:
             self._ck(self._lib.msnap_solve_batch(
                 self._h, N, M, pwp, pt, shared, coef.ctypes.data_as(ctypes.c_void_p),
@@ -151,7 +192,7 @@ class Context:
         self._grid_m = int(n_seg) + 1
         self._grid_host = None
 
-    def solve_grid(self, wp):
+    def solve_grid(self, wp, out=None):
         """wp [N, m, 4] on the prepared grid -> coef, dur, status (as solve_batch)."""
         wp, pwp = _host(wp, np.float64)
         m = getattr(self, "_grid_m", None)
@@ -160,9 +201,7 @@ class Context:
         if wp.ndim != 3 or wp.shape[1:] != (m, 4):
             raise ValueError(f"wp must be [N, {m}, 4] for the prepared grid")
         N, M = wp.shape[0], m - 1
-        coef = np.empty((N, M, 4, self.ncoef), dtype=np.float64)
-        dur = np.empty((N, M), dtype=np.float64)
-        status = np.empty((N,), dtype=np.int32)
+        coef, dur, status = _out_arrays(out, ((N, M, 4, self.ncoef), (N, M), (N,)))
         with self._lock:
             self._ck(self._lib.msnap_solve_grid(self._h, N, pwp, coef.ctypes.data_as(ctypes.c_void_p),
                                                dur.ctypes.data_as(ctypes.c_void_p),

@@ -80,6 +80,8 @@ int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
   {
     const char *e = getenv("MSNAP_NO_TWIST");
     ctx->no_twist = (e && e[0] == '1') ? 1 : 0;
+    e = getenv("MSNAP_PIPE_CHUNK_MB");
+    if (e && atol(e) > 0) ctx->pipe_chunk_bytes = (size_t)atol(e) << 20;
   }
   int rc = MSNAP_OK;
   do {
@@ -108,6 +110,13 @@ void msnap_destroy(msnap_ctx *ctx) {
     if (b->p) (void)hipFree(b->p);
   for (auto &b : ctx->stage)
     if (b.p) (void)hipFree(b.p);
+  for (int k = 0; k < 2; ++k) {
+    if (ctx->pipe_stream[k]) (void)hipStreamSynchronize(ctx->pipe_stream[k]);
+    for (auto &b : ctx->pipe[k])
+      if (b.p) (void)hipFree(b.p);
+    if (ctx->pipe_stream[k]) (void)hipStreamDestroy(ctx->pipe_stream[k]);
+  }
+  if (ctx->pipe_start) (void)hipEventDestroy(ctx->pipe_start);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -124,6 +133,24 @@ int msnap_use_own_stream(msnap_ctx *ctx) {
   if (!ctx) return MSNAP_EINVAL;
   ctx->stream = ctx->own_stream;
   return MSNAP_OK;
+}
+
+int msnap_host_alloc(void **ptr, size_t bytes) {
+  if (!ptr) return MSNAP_EINVAL;
+  *ptr = nullptr;
+  if (bytes == 0) return MSNAP_OK;
+  hipError_t e = hipHostMalloc(ptr, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *ptr = nullptr;
+    (void)hipGetLastError();
+    return e == hipErrorNoDevice ? MSNAP_ENODEVICE : MSNAP_ENOMEM;
+  }
+  return MSNAP_OK;
+}
+
+int msnap_host_free(void *ptr) {
+  if (!ptr) return MSNAP_OK;
+  return hipHostFree(ptr) == hipSuccess ? MSNAP_OK : MSNAP_EHIP;
 }
 
 void *msnap_get_stream(msnap_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -149,6 +176,105 @@ int msnap_timer_stop(msnap_ctx *ctx, float *elapsed_ms) {
 }
 
 // ------------------------------------------------------------------ solve
+// Host-pointer solve (msnap_solve_batch / msnap_solve_grid): H2D, kernel, D2H.
+// Batches whose coefficients exceed one chunk (ctx->pipe_chunk_bytes) are cut into chunks of
+// drones that alternate between two streams, each with its own device staging set, so chunk
+// c+1's upload and kernel overlap chunk c's download; with page-locked host buffers
+// (msnap_host_alloc) both copy engines then run at PCIe rate, with pageable memory the HIP
+// runtime serialises the copies and the result is the same as one big copy.  Device staging is
+// bounded by two chunks, whatever the batch size.
+static int solve_host(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, const double *t, int shared,
+                      bool use_grid, double *coef, double *dur, int32_t *status) {
+  const size_t m = (size_t)n_seg + 1, nc = ctx->order + 1;
+  const size_t pd_wp = m * 4 * 8, pd_t = m * 8;                       // bytes per drone
+  const size_t pd_coef = (size_t)n_seg * 4 * nc * 8, pd_dur = (size_t)n_seg * 8, pd_st = 4;
+  size_t chunk = ctx->pipe_chunk_bytes / pd_coef;
+  chunk -= chunk % kDronesPerWave;
+  if (chunk < 4096) chunk = 4096;
+  const size_t N = n_drones;
+  int rc;
+  auto launch = [&](size_t n, const double *dwp, const double *dt, double *dcoef, double *ddur, int32_t *dst) {
+    return use_grid ? launch_solve_grid(ctx, (int)n, dwp, dcoef, ddur, dst)
+                    : launch_solve(ctx, (int)n, n_seg, dwp, dt, shared, dcoef, ddur, dst);
+  };
+  if (N <= chunk || solve_uses_global_scratch(ctx, n_seg)) {
+    // one shot on the context's stream
+    if ((rc = ensure(ctx, ctx->stage[0], N * pd_wp))) return rc;
+    if (t && (rc = ensure(ctx, ctx->stage[1], (shared ? 1 : N) * pd_t))) return rc;
+    if ((rc = ensure(ctx, ctx->stage[2], N * pd_coef))) return rc;
+    if ((rc = ensure(ctx, ctx->stage[3], N * pd_dur))) return rc;
+    if ((rc = ensure(ctx, ctx->stage[4], N * pd_st))) return rc;
+    MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, wp, N * pd_wp, hipMemcpyHostToDevice, ctx->stream));
+    if (t)
+      MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, t, (shared ? 1 : N) * pd_t, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    rc = launch(N, (const double *)ctx->stage[0].p, (const double *)ctx->stage[1].p, (double *)ctx->stage[2].p,
+                (double *)ctx->stage[3].p, (int32_t *)ctx->stage[4].p);
+    if (rc) return rc;
+    MSNAP_HIP(ctx, hipMemcpyAsync(coef, ctx->stage[2].p, N * pd_coef, hipMemcpyDeviceToHost, ctx->stream));
+    MSNAP_HIP(ctx, hipMemcpyAsync(dur, ctx->stage[3].p, N * pd_dur, hipMemcpyDeviceToHost, ctx->stream));
+    MSNAP_HIP(ctx, hipMemcpyAsync(status, ctx->stage[4].p, N * pd_st, hipMemcpyDeviceToHost, ctx->stream));
+    MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MSNAP_OK;
+  }
+
+  for (int k = 0; k < 2; ++k)
+    if (!ctx->pipe_stream[k])
+      MSNAP_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe_stream[k], hipStreamNonBlocking));
+  if (!ctx->pipe_start) MSNAP_HIP(ctx, hipEventCreateWithFlags(&ctx->pipe_start, hipEventDisableTiming));
+  const bool per_drone_t = t && !shared;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = ensure(ctx, ctx->pipe[k][0], chunk * pd_wp))) return rc;
+    if (per_drone_t && (rc = ensure(ctx, ctx->pipe[k][1], chunk * pd_t))) return rc;
+    if ((rc = ensure(ctx, ctx->pipe[k][2], chunk * pd_coef))) return rc;
+    if ((rc = ensure(ctx, ctx->pipe[k][3], chunk * pd_dur))) return rc;
+    if ((rc = ensure(ctx, ctx->pipe[k][4], chunk * pd_st))) return rc;
+  }
+  if (t && shared) {
+    if ((rc = ensure(ctx, ctx->stage[1], pd_t))) return rc;
+    MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, t, pd_t, hipMemcpyHostToDevice, ctx->stream));
+  }
+  // the chunk streams start after whatever the context's stream holds (incl. the shared grid upload)
+  MSNAP_HIP(ctx, hipEventRecord(ctx->pipe_start, ctx->stream));
+  hipStream_t const user_stream = ctx->stream;
+  rc = MSNAP_OK;
+  hipError_t herr = hipSuccess;
+  const char *what = "";
+#define PIPE_HIP(call)                                   \
+  if (rc == MSNAP_OK && herr == hipSuccess) {            \
+    herr = (call);                                       \
+    if (herr != hipSuccess) what = #call;                \
+  }
+  for (int k = 0; k < 2; ++k) PIPE_HIP(hipStreamWaitEvent(ctx->pipe_stream[k], ctx->pipe_start, 0));
+  size_t c = 0;
+  for (size_t d0 = 0; d0 < N && rc == MSNAP_OK && herr == hipSuccess; d0 += chunk, ++c) {
+    const size_t n = (N - d0 < chunk) ? N - d0 : chunk;
+    const int k = (int)(c & 1);
+    hipStream_t s = ctx->pipe_stream[k];
+    DevBuf *b = ctx->pipe[k];
+    PIPE_HIP(hipMemcpyAsync(b[0].p, (const char *)wp + d0 * pd_wp, n * pd_wp, hipMemcpyHostToDevice, s));
+    if (per_drone_t)
+      PIPE_HIP(hipMemcpyAsync(b[1].p, (const char *)t + d0 * pd_t, n * pd_t, hipMemcpyHostToDevice, s));
+    if (herr != hipSuccess) break;
+    ctx->stream = s;   // the launchers enqueue on ctx->stream
+    rc = launch(n, (const double *)b[0].p, per_drone_t ? (const double *)b[1].p : (const double *)ctx->stage[1].p,
+                (double *)b[2].p, (double *)b[3].p, (int32_t *)b[4].p);
+    ctx->stream = user_stream;
+    PIPE_HIP(hipMemcpyAsync((char *)coef + d0 * pd_coef, b[2].p, n * pd_coef, hipMemcpyDeviceToHost, s));
+    PIPE_HIP(hipMemcpyAsync((char *)dur + d0 * pd_dur, b[3].p, n * pd_dur, hipMemcpyDeviceToHost, s));
+    PIPE_HIP(hipMemcpyAsync((char *)status + d0 * pd_st, b[4].p, n * pd_st, hipMemcpyDeviceToHost, s));
+  }
+#undef PIPE_HIP
+  // always drain both streams, also on the error path: the staging sets must be idle on return
+  for (int k = 0; k < 2; ++k) {
+    hipError_t e = hipStreamSynchronize(ctx->pipe_stream[k]);
+    if (herr == hipSuccess && e != hipSuccess) { herr = e; what = "hipStreamSynchronize(pipe)"; }
+  }
+  if (rc != MSNAP_OK) return rc;
+  if (herr != hipSuccess) return record_hip_error(ctx, herr, what);
+  return MSNAP_OK;
+}
+
 int msnap_solve_batch_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
                              const double *t, int shared_times, double *coef, double *dur,
                              int32_t *status) {
@@ -169,25 +295,7 @@ int msnap_solve_batch(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
   if (n_drones == 0) return MSNAP_OK;
   if (!wp || !t || !coef || !dur || !status) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t N = n_drones, m = (size_t)n_seg + 1, nc = ctx->order + 1;
-  const size_t b_wp = N * m * 4 * 8, b_t = (shared_times ? 1 : N) * m * 8;
-  const size_t b_coef = N * n_seg * 4 * nc * 8, b_dur = N * n_seg * 8, b_st = N * 4;
-  if ((rc = ensure(ctx, ctx->stage[0], b_wp))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[1], b_t))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[2], b_coef))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[3], b_dur))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[4], b_st))) return rc;
-  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, wp, b_wp, hipMemcpyHostToDevice, ctx->stream));
-  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, t, b_t, hipMemcpyHostToDevice, ctx->stream));
-  rc = launch_solve(ctx, n_drones, n_seg, (const double *)ctx->stage[0].p, (const double *)ctx->stage[1].p,
-                    shared_times ? 1 : 0, (double *)ctx->stage[2].p, (double *)ctx->stage[3].p,
-                    (int32_t *)ctx->stage[4].p);
-  if (rc) return rc;
-  MSNAP_HIP(ctx, hipMemcpyAsync(coef, ctx->stage[2].p, b_coef, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipMemcpyAsync(dur, ctx->stage[3].p, b_dur, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipMemcpyAsync(status, ctx->stage[4].p, b_st, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MSNAP_OK;
+  return solve_host(ctx, n_drones, n_seg, wp, t, shared_times ? 1 : 0, /*use_grid=*/false, coef, dur, status);
 }
 
 // ------------------------------------------------------------------ shared grid (K2)
@@ -227,24 +335,7 @@ int msnap_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coe
   if (n_drones == 0) return MSNAP_OK;
   if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  const int n_seg = ctx->grid_seg;
-  const size_t N = n_drones, m = (size_t)n_seg + 1, nc = ctx->order + 1;
-  const size_t b_wp = N * m * 4 * 8;
-  const size_t b_coef = N * n_seg * 4 * nc * 8, b_dur = N * n_seg * 8, b_st = N * 4;
-  int rc;
-  if ((rc = ensure(ctx, ctx->stage[0], b_wp))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[2], b_coef))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[3], b_dur))) return rc;
-  if ((rc = ensure(ctx, ctx->stage[4], b_st))) return rc;
-  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, wp, b_wp, hipMemcpyHostToDevice, ctx->stream));
-  rc = launch_solve_grid(ctx, n_drones, (const double *)ctx->stage[0].p, (double *)ctx->stage[2].p,
-                         (double *)ctx->stage[3].p, (int32_t *)ctx->stage[4].p);
-  if (rc) return rc;
-  MSNAP_HIP(ctx, hipMemcpyAsync(coef, ctx->stage[2].p, b_coef, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipMemcpyAsync(dur, ctx->stage[3].p, b_dur, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipMemcpyAsync(status, ctx->stage[4].p, b_st, hipMemcpyDeviceToHost, ctx->stream));
-  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MSNAP_OK;
+  return solve_host(ctx, n_drones, ctx->grid_seg, wp, nullptr, 1, /*use_grid=*/true, coef, dur, status);
 }
 
 // ------------------------------------------------------------------ pack

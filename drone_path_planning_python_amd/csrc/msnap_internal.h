@@ -46,6 +46,12 @@ struct msnap_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   msnap::DevBuf scratch;   // global-memory scratch for n_seg too large for LDS
   msnap::DevBuf stage[8];  // device staging for the host-pointer entry points
+  // chunked host-pointer solves: two streams alternate H2D -> kernel -> D2H over chunks of drones,
+  // each with its own staging set (wp, t, coef, dur, status)
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  hipEvent_t pipe_start = nullptr;
+  msnap::DevBuf pipe[2][5];
+  size_t pipe_chunk_bytes = 64u << 20;   // output bytes per chunk (MSNAP_PIPE_CHUNK_MB overrides)
   // shared-time-grid operator (K2): built by msnap_grid_prepare
   msnap::DevBuf grid_t, grid_wp, grid_op, grid_dur, grid_status, grid_frag;
   int grid_seg = 0;
@@ -85,6 +91,9 @@ int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double 
 int launch_mesh_validity(msnap_ctx *ctx, int n_states, const double *states, int n_rtris, const double *rtris,
                          int n_etris, const double *etris, int32_t *valid);
 int solve_kernel_setup(msnap_ctx *ctx);
+// true when launch_solve would use the context's single global scratch slab (very long paths):
+// such launches must not overlap each other
+bool solve_uses_global_scratch(const msnap_ctx *ctx, int n_seg);
 int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device);
 int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
                       int32_t *status);

@@ -1299,6 +1299,13 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   return MSNAP_OK;
 }
 
+bool solve_uses_global_scratch(const msnap_ctx *ctx, int n_seg) {
+  if (n_seg <= kRegMaxSeg2) return false;
+  const size_t tr_bytes = (size_t)ctx->khalf * kTrPitch * 16;
+  return tr_bytes + (solve_scratch_words(ctx->khalf, n_seg) + solve_input_words(n_seg)) * sizeof(double) >
+         kMaxLdsBytes;
+}
+
 int solve_kernel_setup(msnap_ctx *ctx) {
   // allow the full 160 KiB of dynamic LDS
   MSNAP_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<4, false>),

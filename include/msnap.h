@@ -10,8 +10,10 @@
  *
  * Conventions
  *   - all arrays row-major, caller-owned, fp64 unless noted;
- *   - entry points WITHOUT a suffix take HOST pointers (staged through the
- *     context's pinned buffers, synchronous);
+ *   - entry points WITHOUT a suffix take HOST pointers and are synchronous (device
+ *     staging owned by the context; the two solve entry points cut large batches
+ *     into chunks that overlap upload, kernel and download -- at full PCIe rate when
+ *     the host buffers come from msnap_host_alloc, correct with any host memory);
  *   - entry points ending in _device take DEVICE pointers, are asynchronous on
  *     the context's stream (msnap_sync / stream order to observe results);
  *   - order = polynomial degree, 7 (minimum snap, the reference) or 9
@@ -28,6 +30,7 @@
 #ifndef MSNAP_H
 #define MSNAP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -67,6 +70,11 @@ int msnap_set_stream(msnap_ctx *ctx, void *hip_stream);
 int msnap_use_own_stream(msnap_ctx *ctx);
 void *msnap_get_stream(msnap_ctx *ctx);
 int msnap_sync(msnap_ctx *ctx);
+/* Page-locked host memory for the host-pointer entry points (the reference's arrays
+ * are ordinary NumPy allocations, src/optimizations/calculatingTrajectories.py:137-144;
+ * pinned ones let the copy engines read and write them directly). */
+int msnap_host_alloc(void **ptr, size_t bytes);
+int msnap_host_free(void *ptr);
 /* hipEvent timing on the context's stream (bench.py roofline leg). */
 int msnap_timer_start(msnap_ctx *ctx);
 int msnap_timer_stop(msnap_ctx *ctx, float *elapsed_ms);   /* synchronises */

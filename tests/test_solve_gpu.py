@@ -392,3 +392,78 @@ def test_uneven_segment_lengths(ctx7, seed):
             num = np.abs(coef[d, :, a, :] - ref).max()
             # observed worst case 1.5e-8 (1:200 length ratios); the gate is the north-star's 1e-6
             assert num / np.abs(ref).max() <= 1e-6, (d, a, num / np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------
+# host-pointer boundary: chunked upload / kernel / download pipeline, page-locked buffers
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("n", [4096 + 1, 3 * 4096, 5 * 4096 + 777])
+def test_chunked_host_solve_is_bitwise_the_single_shot_solve(n, shared, monkeypatch):
+    """Batches above one chunk are cut into chunks of drones that alternate between two
+    streams.  With the smallest chunk (4096 drones) the result must be bit-identical to the
+    device-pointer solve of the whole batch, for pageable and for page-locked host arrays."""
+    import torch
+    from drone_path_planning_python_amd import Context, pinned_empty
+    from drone_path_planning_python_amd.synthetic import swarm
+    M = 6
+    wp, t = swarm(900, n, M)
+    if shared:
+        t = np.ascontiguousarray(t[0])
+    monkeypatch.setenv("MSNAP_PIPE_CHUNK_MB", "1")     # 1 MB / 1536 B per drone < 4096 -> chunk = 4096 drones
+    monkeypatch.setenv("MSNAP_NO_TWIST", "1")          # chunks and whole batch on the same kernel variant
+    with Context(order=7, max_segments=16) as ctx:
+        dev = torch.device("cuda:0")
+        dwp, dt = torch.from_numpy(wp).to(dev), torch.from_numpy(t).to(dev)
+        dcoef = torch.empty((n, M, 4, 8), dtype=torch.float64, device=dev)
+        ddur = torch.empty((n, M), dtype=torch.float64, device=dev)
+        dst = torch.empty((n,), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.solve_batch_device(n, M, dwp, dt, shared, dcoef, ddur, dst)
+        ctx.sync()
+        ref = (dcoef.cpu().numpy(), ddur.cpu().numpy(), dst.cpu().numpy())
+        got = ctx.solve_batch(wp, t)                                  # pageable in and out
+        for g, r in zip(got, ref):
+            np.testing.assert_array_equal(g, r)
+        pwp, pt = pinned_empty(wp.shape), pinned_empty(t.shape)
+        pwp[...] = wp
+        pt[...] = t
+        out = (pinned_empty((n, M, 4, 8)), pinned_empty((n, M)), pinned_empty((n,), np.int32))
+        for a in out:
+            a.view(np.uint8)[...] = 0xA5
+        res = ctx.solve_batch(pwp, pt, out=out)                       # page-locked in and out
+        assert all(r is o for r, o in zip(res, out))
+        for g, r in zip(out, ref):
+            np.testing.assert_array_equal(g, r)
+        # the shared-grid GEMM path goes through the same pipeline
+        if shared:
+            ctx.prepare_grid(t)
+            gc, gd, gs = ctx.solve_grid(pwp, out=out)
+            assert (gs == 0).all() and norm_rel(gc, ref[0]) <= 1e-11
+            np.testing.assert_array_equal(gd, ref[1])
+
+
+def test_out_argument_is_validated(ctx7):
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(901, 5, 4)
+    good = (np.empty((5, 4, 4, 8)), np.empty((5, 4)), np.empty((5,), np.int32))
+    ctx7.solve_batch(wp, t, out=good)
+    for bad in [(good[0], good[1]),
+                (np.empty((5, 4, 4, 8), np.float32), good[1], good[2]),
+                (np.empty((5, 4, 4, 9)), good[1], good[2]),
+                (good[0], good[1], np.empty((5,), np.int64)),
+                (np.empty((8, 4, 5, 4)).transpose(3, 1, 2, 0)[:5], good[1], good[2])]:
+        with pytest.raises(ValueError):
+            ctx7.solve_batch(wp, t, out=bad)
+
+
+def test_pinned_arrays_outlive_their_views():
+    import gc
+    from drone_path_planning_python_amd import pinned_empty
+    a = pinned_empty((128, 3))
+    a[...] = 1.5
+    row = a[7]
+    del a
+    gc.collect()
+    assert (row == 1.5).all()
+    assert pinned_empty((0, 4)).shape == (0, 4)
