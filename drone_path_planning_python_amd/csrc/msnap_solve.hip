@@ -32,6 +32,8 @@
 //   solve_kernel<K, false>     any n_seg whose stash fits 160 KiB: rolled loops, LDS stash
 //   solve_kernel<K, true>      longer paths: stash on a global scratch slab
 #include "msnap_consts.h"
+#include <cstdlib>
+
 #include "msnap_internal.h"
 
 namespace msnap {
@@ -932,6 +934,21 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 // ------------------------------------------------------------------------------------
 constexpr int kTwistDrones = 8;
 
+#ifdef MSNAP_EXPERIMENT_TIMELINE
+// phase timestamps of the twisted kernel (s_memrealtime, 100 MHz, and s_memtime): tools/twist_timeline.py
+__device__ unsigned long long g_timeline[1024 * 32];
+#define MSNAP_TL(k)                                                                       \
+  do {                                                                                    \
+    const int it__ = (tl_tile - (int)blockIdx.x) / (int)gridDim.x;                        \
+    if (lane == 0 && blockIdx.x < 1024 && it__ < 2) {                                     \
+      g_timeline[blockIdx.x * 32 + 16 * it__ + 2 * (k)] = wall_clock64();                 \
+      g_timeline[blockIdx.x * 32 + 16 * it__ + 2 * (k) + 1] = clock64();                  \
+    }                                                                                     \
+  } while (0)
+#else
+#define MSNAP_TL(k) do { } while (0)
+#endif
+
 template <int MAXH>
 __global__ void __launch_bounds__(kWave)
 solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
@@ -957,6 +974,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   double *sG = sTraw + kTwistDrones * tpitch;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifdef MSNAP_EXPERIMENT_TIMELINE
+    const int tl_tile = tile;
+#endif
+    MSNAP_TL(0);
     const int d_raw = tile * kTwistDrones + dl;
     const bool live = d_raw < N;
     const int d = live ? d_raw : N - 1;
@@ -999,6 +1020,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       }
     }
     __syncthreads();
+    MSNAP_TL(1);
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
 
     const int dloc = live ? dl : (N - 1 - tile * kTwistDrones);
@@ -1012,6 +1034,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     };
 
     double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[MAXH][NU];
+    // a launch of this kernel never has more than two waves per CU, so the short instance keeps the
+    // G_i blocks in registers too (no LDS round trip on the dependent chain); the long one stashes them
+    constexpr bool kGReg = MAXH <= 6;
+    double Greg[kGReg ? MAXH : 1][NU][NU];
     double Gl[NU][NU], zl[NU];
     const double t0 = lt[0];
     wreg[0] = Wown(0);
@@ -1048,7 +1074,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
             zl[r] = z[r];
 #pragma unroll
             for (int c = 0; c < NU; ++c) {
-              g[(r * NU + c) * 16] = G[r][c];
+              if constexpr (kGReg) Greg[it - 1][r][c] = G[r][c];
+              else g[(r * NU + c) * 16] = G[r][c];
               Gl[r][c] = G[r][c];
             }
           }
@@ -1056,6 +1083,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       }
     }
 
+    MSNAP_TL(2);
     // per-drone status over the 8 lanes (2 sides x 4 axes)
     int flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (sw.singular ? 1 : 0);
     flags |= __shfl_xor(flags, 1);
@@ -1113,28 +1141,39 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       unext[r] = dsg[r] * v;
     }
 
+    MSNAP_TL(3);
     // ---- outward back-substitution + recovery; side 0 also owns the middle segment ----
+    // A failed drone's outputs are NaN: poison what every coefficient is computed from once
+    // (waypoints -> c0 and the end-side block, knot states -> c1..c3) instead of selecting per piece.
+    const double qnan = __builtin_nan("");
+    const double zero_or_nan = bad ? qnan : 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXH + 2; ++i) wreg[i] = bad ? qnan : wreg[i];
     const int top = side ? mside - 1 : mside;
     double un[NU];
 #pragma unroll
-    for (int r = 0; r < NU; ++r) un[r] = side ? ulast[r] : unext[r];
+    for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : (side ? ulast[r] : unext[r]);
 #pragma unroll
     for (int it = MAXH; it >= 0; --it) {
       if (it <= mmax) {          // wave-uniform (top <= mmax)
         if (it <= top) {         // per side; the 4 axis lanes of a quad agree
           double u[NU];
           if (it >= 1) {
+            // side 0 at its last knot: this is the merge's first equation, u_a = z_a - G_a u_b
             const double *g = sG + (it - 1) * (NU * NU * 16) + hd;
 #pragma unroll
             for (int r = 0; r < NU; ++r) {
               double v = zreg[it >= 1 ? it - 1 : 0][r];
 #pragma unroll
-              for (int c = 0; c < NU; ++c) v = __builtin_fma(-g[(r * NU + c) * 16], un[c], v);
-              u[r] = (side == 0 && it == mside) ? ulast[r] : v;
+              for (int c = 0; c < NU; ++c) {
+                const double gv = kGReg ? Greg[it >= 1 ? it - 1 : 0][r][c] : g[(r * NU + c) * 16];
+                v = __builtin_fma(-gv, un[c], v);
+              }
+              u[r] = v;
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < NU; ++r) u[r] = 0.0;
+            for (int r = 0; r < NU; ++r) u[r] = zero_or_nan;
           }
           // Side 1 holds the piece in reversed time, q(s) with p(t) = q(T - t).  Its endpoint states in
           // forward time are the reversed ones with the odd derivatives negated, so the forward
@@ -1152,10 +1191,6 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
           if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
           const int seg = side ? M - 1 - it : it;
           // a batch this small is latency bound, not store bound: plain per-lane stores
-          if (bad) {
-#pragma unroll
-            for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
-          }
           if (live) {
             double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
 #pragma unroll
@@ -1166,6 +1201,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
         }
       }
     }
+    MSNAP_TL(4);
   }
 }
 
@@ -1185,6 +1221,12 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int mR = (M - 1) - (M - 1) / 2;
     const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR) * sizeof(double);
+#ifdef MSNAP_EXPERIMENT_TIMELINE
+    if (M <= 2 * kTwistMaxHalf && getenv("MSNAP_TL_HALF_GRID"))   // two tiles per wave: is the 2nd one faster (warm I$)?
+      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3((nt8 + 1) / 2), dim3(kWave), lds_bytes,
+                         ctx->stream, wp, t, shared, N, M, coef, dur, status, nt8);
+    else
+#endif
     if (M <= 2 * kTwistMaxHalf)
       hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp,
                          t, shared, N, M, coef, dur, status, nt8);
@@ -1238,6 +1280,13 @@ bool solve_uses_global_scratch(const msnap_ctx *ctx, int n_seg) {
   return tr_bytes + (solve_scratch_words(ctx->khalf, n_seg) + solve_input_words(n_seg)) * sizeof(double) >
          kMaxLdsBytes;
 }
+
+#ifdef MSNAP_EXPERIMENT_TIMELINE
+extern "C" int msnap_debug_read_timeline(unsigned long long *out, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return MSNAP_EHIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n_words * 8) == hipSuccess ? MSNAP_OK : MSNAP_EHIP;
+}
+#endif
 
 int solve_kernel_setup(msnap_ctx *ctx) {
   // allow the full 160 KiB of dynamic LDS
