@@ -66,7 +66,7 @@ def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) ->
     k = (order + 1) // 2
     ntiles = (n_drones + 15) // 16
     if k == 4 and 3 <= n_seg <= 24 and ntiles <= n_cu:
-        return "msnap::solve_kernel_twist<%d>" % (6 if n_seg <= 12 else 12)
+        return "msnap::solve_kernel_twist<%d, %d>" % ((n_seg - 1) - (n_seg - 1) // 2, n_seg)
     if n_seg <= 20:
         return "msnap::solve_kernel_reg<%d, %d>" % (k, 10 if n_seg <= 10 else 20)
     return "msnap::solve_kernel<%d, false>" % k

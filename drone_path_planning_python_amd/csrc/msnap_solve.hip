@@ -24,8 +24,9 @@
 // same M-step recurrence).  The tile's inputs are staged in LDS by one
 // coalesced sweep.  The variants share the arithmetic (Sweep<K>::step, recover_segment)
 // and are chosen per launch by launch_solve_k:
-//   solve_kernel_twist<6|12>   order 7, 3 <= n_seg <= 24, batch below one wavefront per CU:
-//                              two-sided sweep, halves the dependent chain   (latency path)
+//   solve_kernel_twist<H,M>    order 7, 3 <= n_seg <= 24, batch below one wavefront per CU:
+//                              two-sided sweep (halves the dependent chain), one straight-line
+//                              instance per n_seg                            (latency path)
 //   solve_kernel_reg<K,10|20>  n_seg <= 20: knot loops unrolled, path data and z_i in
 //                              registers, G_i in LDS, persistent waves with cross-tile
 //                              input prefetch                               (throughput path)
@@ -103,31 +104,59 @@ struct Sweep {
     for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
   }
 
-  // knot i with segment i (x = 1/T_i, dw = w_{i+1} - w_i) on its right:
-  // S_i = D_i - O_{i-1}^T G_{i-1}, LDL^T, G_i = S_i^-1 O_i, z_i = S_i^-1 y_i
-  __device__ __forceinline__ void step(double x, double dw, double (&G)[NU][NU], double (&z)[NU]) {
+  // Everything of knot i that depends on segment lengths and waypoints only (not on the
+  // recurrence): diagonal block D_i, coupling block O_i, the right-hand side before the Schur
+  // correction, and the end side of segment i for knot i+1.
+  struct Knot {
+    double D[NS], O[NU][NU], yb[NU], E[NS], re[NU];
+  };
+
+  // from segment i (x = 1/T_i, dw = w_{i+1} - w_i) and the end side (Eprev, reprev) of segment i-1
+  __device__ __forceinline__ static void knot_geom(double x, double dw, const double (&Eprev)[NS],
+                                                   const double (&reprev)[NU], Knot &k) {
     double xp[PM + 1];
     powers(x, xp);
+    knot_geom_xp(xp, dw, Eprev, reprev, k);
+  }
 
-    double S[NS], y[NU];
+  // the same from the powers of x = 1/T_i (for callers that prepare them ahead of the recurrence)
+  __device__ __forceinline__ static void knot_geom_xp(const double (&xp)[PM + 1], double dw,
+                                                      const double (&Eprev)[NS], const double (&reprev)[NU],
+                                                      Knot &k) {
 #pragma unroll
     for (int n = 1; n <= NU; ++n) {
 #pragma unroll
       for (int m = 1; m <= n; ++m) {
-        const double v = __builtin_fma(C::HSS[n][m], xp[KK - n - m], E[sidx(n - 1, m - 1)]);
-        S[sidx(n - 1, m - 1)] = v - OtG[sidx(n - 1, m - 1)];
+        k.D[sidx(n - 1, m - 1)] = __builtin_fma(C::HSS[n][m], xp[KK - n - m], Eprev[sidx(n - 1, m - 1)]);
+        k.E[sidx(n - 1, m - 1)] = C::HEE[n][m] * xp[KK - n - m];
       }
-      y[n - 1] = -__builtin_fma(C::HSE[n][0] * xp[KK - n], dw, re[n - 1]) - Otz[n - 1];
+      k.yb[n - 1] = __builtin_fma(C::HSE[n][0] * xp[KK - n], dw, reprev[n - 1]);
+      k.re[n - 1] = (C::HEE[n][0] * xp[KK - n]) * dw;
+#pragma unroll
+      for (int m = 1; m <= NU; ++m) k.O[n - 1][m - 1] = C::HSE[n][m] * xp[KK - n - m];
+    }
+  }
+
+  // the recurrence proper: S_i = D_i - O_{i-1}^T G_{i-1}, LDL^T, G_i = S_i^-1 O_i, z_i = S_i^-1 y_i,
+  // and the Schur terms carried to knot i+1.  Returns false if a pivot is not positive and finite.
+  __device__ __forceinline__ bool chain(const Knot &k, double (&G)[NU][NU], double (&z)[NU]) {
+    double S[NS], y[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) S[sidx(n, m)] = k.D[sidx(n, m)] - OtG[sidx(n, m)];
+      y[n] = -k.yb[n] - Otz[n];
     }
 
     // LDL^T of S; S's strict lower part holds w_rp = L_rp d_p until scaled
+    bool bad = false;
     double dinv[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double dj = S[sidx(j, j)];
 #pragma unroll
       for (int p = 0; p < j; ++p) dj = __builtin_fma(-S[sidx(j, p)] * dinv[p], S[sidx(j, p)], dj);
-      singular |= !(dj > 0.0) | !finite64(dj);   // bitwise: no short-circuit branches
+      bad |= !(dj > 0.0) | !finite64(dj);   // bitwise: no short-circuit branches
       dinv[j] = rcp64(dj);
 #pragma unroll
       for (int r = j + 1; r < NU; ++r) {
@@ -142,18 +171,12 @@ struct Sweep {
 #pragma unroll
       for (int p = 0; p < r; ++p) S[sidx(r, p)] *= dinv[p];
 
-    double O[NU][NU];
-#pragma unroll
-    for (int n = 1; n <= NU; ++n)
-#pragma unroll
-      for (int m = 1; m <= NU; ++m) O[n - 1][m - 1] = C::HSE[n][m] * xp[KK - n - m];
-
     // NU + 1 solves with the factor: columns of O_i, then y
 #pragma unroll
     for (int c = 0; c <= NU; ++c) {
       double v[NU];
 #pragma unroll
-      for (int r = 0; r < NU; ++r) v[r] = (c < NU) ? O[r][c < NU ? c : 0] : y[r];
+      for (int r = 0; r < NU; ++r) v[r] = (c < NU) ? k.O[r][c < NU ? c : 0] : y[r];
 #pragma unroll
       for (int r = 1; r < NU; ++r)
 #pragma unroll
@@ -171,22 +194,33 @@ struct Sweep {
       }
     }
 
-    // carry to knot i+1: the end side of segment i and the Schur terms O_i^T G_i, O_i^T z_i
-    end_side(xp, dw);
+    // carry to knot i+1: the Schur terms O_i^T G_i, O_i^T z_i
 #pragma unroll
     for (int n = 0; n < NU; ++n) {
 #pragma unroll
       for (int m = 0; m <= n; ++m) {
         double v = 0.0;
 #pragma unroll
-        for (int q = 0; q < NU; ++q) v = __builtin_fma(O[q][n], G[q][m], v);
+        for (int q = 0; q < NU; ++q) v = __builtin_fma(k.O[q][n], G[q][m], v);
         OtG[sidx(n, m)] = v;
       }
       double w = 0.0;
 #pragma unroll
-      for (int q = 0; q < NU; ++q) w = __builtin_fma(O[q][n], z[q], w);
+      for (int q = 0; q < NU; ++q) w = __builtin_fma(k.O[q][n], z[q], w);
       Otz[n] = w;
     }
+    return !bad;
+  }
+
+  // knot i with segment i (x = 1/T_i, dw = w_{i+1} - w_i) on its right: geometry, then recurrence
+  __device__ __forceinline__ void step(double x, double dw, double (&G)[NU][NU], double (&z)[NU]) {
+    Knot k;
+    knot_geom(x, dw, E, re, k);
+    singular |= !chain(k, G, z);
+#pragma unroll
+    for (int e = 0; e < NS; ++e) E[e] = k.E[e];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) re[r] = k.re[r];
   }
 };
 
@@ -933,6 +967,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 // the segment length and a sign flip of the odd coefficients (p(t) = q(T - t)).
 // ------------------------------------------------------------------------------------
 constexpr int kTwistDrones = 8;
+constexpr int kTwistFenceHalf = 9;   // instances with this many knots per side fence the scheduler per knot
 
 #ifdef MSNAP_EXPERIMENT_TIMELINE
 // phase timestamps of the twisted kernel (s_memrealtime, 100 MHz, and s_memtime): tools/twist_timeline.py
@@ -949,13 +984,17 @@ __device__ unsigned long long g_timeline[1024 * 32];
 #define MSNAP_TL(k) do { } while (0)
 #endif
 
-template <int MAXH>
+// One instance per segment count M (MAXH = knots on the longer side): every loop bound is a
+// constant, so the whole solve is straight-line code that the scheduler interleaves across knots
+// (a run-time M costs block boundaries with dozens of register copies each: 6.2 vs 5.3 us at M = 10).
+template <int MAXH, int M>
 __global__ void __launch_bounds__(kWave)
 solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
-                   int N, int M, double *__restrict__ coef, double *__restrict__ dur,
+                   int N, double *__restrict__ coef, double *__restrict__ dur,
                    int32_t *__restrict__ status, int ntiles) {
   using SW = Sweep<4>;
   constexpr int NU = 3, NC = 8;
+  static_assert(M >= 3 && MAXH == (M - 1) - (M - 1) / 2, "MAXH is the knot count of the longer side");
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -1033,7 +1072,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       return lt[j + 1] - lt[j];
     };
 
-    double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[MAXH][NU];
+    // long paths keep z_i in LDS as well (one slot per lane) so the instance fits the register file
+    constexpr bool kZReg = MAXH < kTwistFenceHalf + 1;
+    double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[kZReg ? MAXH : 1][NU];
+    double *sZ = sG + 16 * NU * NU * mmax + lane;      // [knot][r][64 lanes]
     // a launch of this kernel never has more than two waves per CU, so the short instance keeps the
     // G_i blocks in registers too (no LDS round trip on the dependent chain); the long one stashes them
     constexpr bool kGReg = MAXH <= 6;
@@ -1056,40 +1098,94 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       for (int c = 0; c < NU; ++c) Gl[r][c] = 0.0;
     }
 
+    // A lone wave is bound by instruction issue and dependent latency, so each knot's geometry
+    // (1/T, its powers, D, O, the right-hand side: independent of the recurrence) is computed one
+    // knot AHEAD, inside the same basic block as the previous knot's recurrence, where the
+    // scheduler can fill the recurrence's latency bubbles with it.  All lanes run all mmax steps
+    // (side 0 may own one knot less: its extra step works on valid data and is not committed).
+    // Per knot, the long dependent prefix that does not involve the recurrence -- inputs from LDS,
+    // T, 1/T (reciprocal + Newton), its powers -- is prepared one knot AHEAD, inside the same
+    // basic block as the previous knot's recurrence, where it fills that chain's latency bubbles.
+    // All lanes run all mmax steps (side 0 may own one knot less: its extra step works on valid
+    // data and is not committed).
+    double xpc[SW::PM + 1], dwc;     // powers of 1/T_it and w_{it+1} - w_it of the current knot
+    auto ahead = [&](int it, double (&xp)[SW::PM + 1], double &dw) {
+      wreg[it + 1] = Wown(it + 1);
+      Treg[it] = Town(it);
+      nonfinite |= !finite64(Treg[it]) | !finite64(wreg[it + 1]);
+      badtime |= !(Treg[it] > 0.0);
+      xreg[it] = rcp64(Treg[it]);
+      SW::powers(xreg[it], xp);
+      dw = wreg[it + 1] - wreg[it];
+    };
+    ahead(1, xpc, dwc);              // M >= 3: knot 1 and segment 1 exist on both sides
+    bool singular = false;
+    auto commit = [&](int it, const double (&G)[NU][NU], const double (&z)[NU]) {
+      double *g = sG + (it - 1) * (NU * NU * 16) + hd;
+#pragma unroll
+      for (int r = 0; r < NU; ++r) {
+        if constexpr (kZReg) zreg[it - 1][r] = z[r];
+        else sZ[((it - 1) * NU + r) * kWave] = z[r];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) {
+          if constexpr (kGReg) Greg[it - 1][r][c] = G[r][c];
+          else if (it <= mside) g[(r * NU + c) * 16] = G[r][c];
+        }
+      }
+    };
+    auto knot_step = [&](int it, double (&G)[NU][NU], double (&z)[NU]) {
+      typename SW::Knot k;
+      SW::knot_geom_xp(xpc, dwc, sw.E, sw.re, k);
+      const bool ok = sw.chain(k, G, z);
+      singular |= !ok & (it <= mside);
+#pragma unroll
+      for (int e = 0; e < SW::NS; ++e) sw.E[e] = k.E[e];
+#pragma unroll
+      for (int r = 0; r < NU; ++r) sw.re[r] = k.re[r];
+      commit(it, G, z);
+    };
 #pragma unroll
     for (int it = 1; it <= MAXH; ++it) {
-      if (it <= mmax) {            // wave-uniform
-        if (it <= mside) {         // per side
-          wreg[it + 1] = Wown(it + 1);
-          Treg[it] = Town(it);
-          nonfinite |= !finite64(Treg[it]) | !finite64(wreg[it + 1]);
-          badtime |= !(Treg[it] > 0.0);
-          xreg[it] = rcp64(Treg[it]);
-          double G[NU][NU], z[NU];
-          sw.step(xreg[it], wreg[it + 1] - wreg[it], G, z);
-          double *g = sG + (it - 1) * (NU * NU * 16) + hd;
+      if (it < mmax) {             // wave-uniform: knot it, and the prefix of knot it+1
+        double G[NU][NU], z[NU], xpn[SW::PM + 1], dwn = 0.0;
+        if (it < MAXH) ahead(it + 1, xpn, dwn);
+        knot_step(it, G, z);
+        if (it < MAXH) {
+          dwc = dwn;
 #pragma unroll
-          for (int r = 0; r < NU; ++r) {
-            zreg[it - 1][r] = z[r];
-            zl[r] = z[r];
+          for (int q = 0; q <= SW::PM; ++q) xpc[q] = xpn[q];
+        }
+        // long paths: keep the scheduler from hoisting several knots' inputs at once (register
+        // pressure beyond the 512-entry file would spill to scratch)
+        if constexpr (MAXH >= kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
+      } else if (it == mmax) {     // last knot, then pick each side's own last knot
+        double G[NU][NU], z[NU];
+        knot_step(it, G, z);
+        const bool own = mside == mmax;    // else this side stopped one knot earlier
 #pragma unroll
-            for (int c = 0; c < NU; ++c) {
-              if constexpr (kGReg) Greg[it - 1][r][c] = G[r][c];
-              else g[(r * NU + c) * 16] = G[r][c];
-              Gl[r][c] = G[r][c];
-            }
+        for (int r = 0; r < NU; ++r) {
+          double zp;
+          if constexpr (kZReg) zp = zreg[it >= 2 ? it - 2 : 0][r];
+          else zp = (it >= 2) ? sZ[((it - 2) * NU + r) * kWave] : 0.0;
+          zl[r] = own ? z[r] : zp;
+#pragma unroll
+          for (int c = 0; c < NU; ++c) {
+            double gp;
+            if constexpr (kGReg) gp = Greg[it >= 2 ? it - 2 : 0][r][c];
+            else gp = (it >= 2) ? sG[(it - 2) * (NU * NU * 16) + hd + (r * NU + c) * 16] : 0.0;
+            Gl[r][c] = own ? G[r][c] : gp;
           }
         }
       }
     }
 
     MSNAP_TL(2);
-    // per-drone status over the 8 lanes (2 sides x 4 axes)
-    int flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (sw.singular ? 1 : 0);
-    flags |= __shfl_xor(flags, 1);
-    flags |= __shfl_xor(flags, 2);
-    flags |= __shfl_xor(flags, 4);
-    const int st = (flags & 4) ? MSNAP_ST_NONFINITE : (flags & 2) ? MSNAP_ST_TIMES : (flags & 1) ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
+    // per-drone status over the 8 lanes (2 sides x 4 axes): wave ballots, no cross-lane round trips
+    const int gsh = lane & ~7;
+    const bool f_nonfinite = ((__ballot(nonfinite) >> gsh) & 0xFFull) != 0;
+    const bool f_time = ((__ballot(badtime) >> gsh) & 0xFFull) != 0;
+    const bool f_sing = ((__ballot(singular) >> gsh) & 0xFFull) != 0;
+    const int st = f_nonfinite ? MSNAP_ST_NONFINITE : f_time ? MSNAP_ST_TIMES : f_sing ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
     if (live && (lane & 7) == 0) status[d] = st;
     const bool bad = st != 0;
 
@@ -1163,7 +1259,9 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
             const double *g = sG + (it - 1) * (NU * NU * 16) + hd;
 #pragma unroll
             for (int r = 0; r < NU; ++r) {
-              double v = zreg[it >= 1 ? it - 1 : 0][r];
+              double v;
+              if constexpr (kZReg) v = zreg[it >= 1 ? it - 1 : 0][r];
+              else v = sZ[((it >= 1 ? it - 1 : 0) * NU + r) * kWave];
 #pragma unroll
               for (int c = 0; c < NU; ++c) {
                 const double gv = kGReg ? Greg[it >= 1 ? it - 1 : 0][r][c] : g[(r * NU + c) * 16];
@@ -1199,14 +1297,14 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 #pragma unroll
           for (int r = 0; r < NU; ++r) un[r] = u[r];
         }
+        if constexpr (MAXH >= kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
       }
     }
     MSNAP_TL(4);
   }
 }
 
-constexpr int kTwistMaxHalf = 6;    // twisted variant: 3 <= n_seg <= 12 ...
-constexpr int kTwistMaxHalf2 = 12;  // ... and 13 <= n_seg <= 24 (one wave per SIMD: > 256 VGPRs)
+constexpr int kTwistMaxSeg = 24;   // twisted variant: one instance per n_seg in 3..24
 
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
@@ -1216,23 +1314,28 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
-  if (K == 4 && M >= 3 && M <= 2 * kTwistMaxHalf2 && ntiles <= ctx->n_cu && !ctx->no_twist) {
+  if (K == 4 && M >= 3 && M <= kTwistMaxSeg && ntiles <= ctx->n_cu && !ctx->no_twist) {
     // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int mR = (M - 1) - (M - 1) / 2;
-    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR) * sizeof(double);
-#ifdef MSNAP_EXPERIMENT_TIMELINE
-    if (M <= 2 * kTwistMaxHalf && getenv("MSNAP_TL_HALF_GRID"))   // two tiles per wave: is the 2nd one faster (warm I$)?
-      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3((nt8 + 1) / 2), dim3(kWave), lds_bytes,
-                         ctx->stream, wp, t, shared, N, M, coef, dur, status, nt8);
-    else
-#endif
-    if (M <= 2 * kTwistMaxHalf)
-      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp,
-                         t, shared, N, M, coef, dur, status, nt8);
-    else
-      hipLaunchKernelGGL((solve_kernel_twist<kTwistMaxHalf2>), dim3(nt8), dim3(kWave), lds_bytes, ctx->stream, wp,
-                         t, shared, N, M, coef, dur, status, nt8);
+    // inputs, G stash (16 (drone,side) x 9 per knot), z stash (64 lanes x 3 per knot; long paths only)
+    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR + (size_t)64 * 3 * mR) *
+                             sizeof(double);
+#define MSNAP_TWIST_EXACT(MM)                                                                          \
+  case MM:                                                                                             \
+    hipLaunchKernelGGL((solve_kernel_twist<(MM - 1) - (MM - 1) / 2, MM>), dim3(nt8), dim3(kWave),      \
+                       lds_bytes, ctx->stream, wp, t, shared, N, coef, dur, status, nt8);             \
+    break;
+    switch (M) {   // 3 <= M <= kTwistMaxSeg
+      MSNAP_TWIST_EXACT(3) MSNAP_TWIST_EXACT(4) MSNAP_TWIST_EXACT(5) MSNAP_TWIST_EXACT(6)
+      MSNAP_TWIST_EXACT(7) MSNAP_TWIST_EXACT(8) MSNAP_TWIST_EXACT(9) MSNAP_TWIST_EXACT(10)
+      MSNAP_TWIST_EXACT(11) MSNAP_TWIST_EXACT(12) MSNAP_TWIST_EXACT(13) MSNAP_TWIST_EXACT(14)
+      MSNAP_TWIST_EXACT(15) MSNAP_TWIST_EXACT(16) MSNAP_TWIST_EXACT(17) MSNAP_TWIST_EXACT(18)
+      MSNAP_TWIST_EXACT(19) MSNAP_TWIST_EXACT(20) MSNAP_TWIST_EXACT(21) MSNAP_TWIST_EXACT(22)
+      MSNAP_TWIST_EXACT(23) MSNAP_TWIST_EXACT(24)
+      default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+    }
+#undef MSNAP_TWIST_EXACT
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
