@@ -1002,7 +1002,6 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   const int a = lane & 3;
   const int side = (lane >> 2) & 1;
   const int dl = lane >> 3;           // drone inside the tile
-  const int hd = lane >> 2;           // (drone, side): 16 per wave, the G stash is per hd
   const int wpitch = (M + 1) * 4;
   const int tpitch = M + 1;
   const int mL = (M - 1) / 2, mR = (M - 1) - mL;      // knots per side, mL <= mR
@@ -1010,7 +1009,6 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   const int mmax = mR;
   double *sWraw = lds;
   double *sTraw = sWraw + kTwistDrones * wpitch;
-  double *sG = sTraw + kTwistDrones * tpitch;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #ifdef MSNAP_EXPERIMENT_TIMELINE
@@ -1073,13 +1071,12 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     };
 
     // long paths keep z_i in LDS as well (one slot per lane) so the instance fits the register file
-    constexpr bool kZReg = MAXH < kTwistFenceHalf + 1;
+    constexpr bool kZReg = MAXH < kTwistFenceHalf;
     double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[kZReg ? MAXH : 1][NU];
-    double *sZ = sG + 16 * NU * NU * mmax + lane;      // [knot][r][64 lanes]
-    // a launch of this kernel never has more than two waves per CU, so the short instance keeps the
-    // G_i blocks in registers too (no LDS round trip on the dependent chain); the long one stashes them
-    constexpr bool kGReg = MAXH <= 6;
-    double Greg[kGReg ? MAXH : 1][NU][NU];
+    double *sZ = sTraw + kTwistDrones * tpitch + lane;      // [knot][r][64 lanes]
+    // a launch of this kernel never has more than two waves per CU: the G_i blocks stay in
+    // registers (overflowing into AGPRs on long paths) -- no LDS round trip on the dependent chain
+    double Greg[MAXH][NU][NU];
     double Gl[NU][NU], zl[NU];
     const double t0 = lt[0];
     wreg[0] = Wown(0);
@@ -1121,16 +1118,12 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     ahead(1, xpc, dwc);              // M >= 3: knot 1 and segment 1 exist on both sides
     bool singular = false;
     auto commit = [&](int it, const double (&G)[NU][NU], const double (&z)[NU]) {
-      double *g = sG + (it - 1) * (NU * NU * 16) + hd;
 #pragma unroll
       for (int r = 0; r < NU; ++r) {
         if constexpr (kZReg) zreg[it - 1][r] = z[r];
         else sZ[((it - 1) * NU + r) * kWave] = z[r];
 #pragma unroll
-        for (int c = 0; c < NU; ++c) {
-          if constexpr (kGReg) Greg[it - 1][r][c] = G[r][c];
-          else if (it <= mside) g[(r * NU + c) * 16] = G[r][c];
-        }
+        for (int c = 0; c < NU; ++c) Greg[it - 1][r][c] = G[r][c];
       }
     };
     auto knot_step = [&](int it, double (&G)[NU][NU], double (&z)[NU]) {
@@ -1169,12 +1162,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
           else zp = (it >= 2) ? sZ[((it - 2) * NU + r) * kWave] : 0.0;
           zl[r] = own ? z[r] : zp;
 #pragma unroll
-          for (int c = 0; c < NU; ++c) {
-            double gp;
-            if constexpr (kGReg) gp = Greg[it >= 2 ? it - 2 : 0][r][c];
-            else gp = (it >= 2) ? sG[(it - 2) * (NU * NU * 16) + hd + (r * NU + c) * 16] : 0.0;
-            Gl[r][c] = own ? G[r][c] : gp;
-          }
+          for (int c = 0; c < NU; ++c) Gl[r][c] = own ? G[r][c] : Greg[it >= 2 ? it - 2 : 0][r][c];
         }
       }
     }
@@ -1256,17 +1244,13 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
           double u[NU];
           if (it >= 1) {
             // side 0 at its last knot: this is the merge's first equation, u_a = z_a - G_a u_b
-            const double *g = sG + (it - 1) * (NU * NU * 16) + hd;
 #pragma unroll
             for (int r = 0; r < NU; ++r) {
               double v;
               if constexpr (kZReg) v = zreg[it >= 1 ? it - 1 : 0][r];
               else v = sZ[((it >= 1 ? it - 1 : 0) * NU + r) * kWave];
 #pragma unroll
-              for (int c = 0; c < NU; ++c) {
-                const double gv = kGReg ? Greg[it >= 1 ? it - 1 : 0][r][c] : g[(r * NU + c) * 16];
-                v = __builtin_fma(-gv, un[c], v);
-              }
+              for (int c = 0; c < NU; ++c) v = __builtin_fma(-Greg[it >= 1 ? it - 1 : 0][r][c], un[c], v);
               u[r] = v;
             }
           } else {
@@ -1318,9 +1302,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int mR = (M - 1) - (M - 1) / 2;
-    // inputs, G stash (16 (drone,side) x 9 per knot), z stash (64 lanes x 3 per knot; long paths only)
-    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)16 * 9 * mR + (size_t)64 * 3 * mR) *
-                             sizeof(double);
+    // inputs + z stash (64 lanes x 3 per knot; used by the long-path instances only)
+    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)64 * 3 * mR) * sizeof(double);
 #define MSNAP_TWIST_EXACT(MM)                                                                          \
   case MM:                                                                                             \
     hipLaunchKernelGGL((solve_kernel_twist<(MM - 1) - (MM - 1) / 2, MM>), dim3(nt8), dim3(kWave),      \
