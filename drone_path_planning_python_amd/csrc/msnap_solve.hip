@@ -225,39 +225,37 @@ struct Sweep {
 };
 
 // monomial coefficients of one segment from its endpoint states
-// (u = d_i[1..k-1], un = d_{i+1}[1..k-1], Ti, xi = 1/Ti, dwi = w_{i+1} - w_i)
+// (u = d_i[1..k-1], un = d_{i+1}[1..k-1], xi = 1/T_i, dwi = w_{i+1} - w_i):
+//   c_{K+m} = x^(K+m) [ CE_m0 dw + sum_n T^n (CS_mn u_n + CE_mn un_n) ]
+//           = x^(m+1) [ CE_m0 dw x^(K-1) + sum_n (CS_mn x^(K-1-n) u_n + CE_mn x^(K-1-n) un_n) ]
+// -- powers of x only, so callers need not keep T_i.
 template <int K>
-__device__ __forceinline__ void recover_segment(double wi, double dwi, double Ti, double xi,
-                                                const double (&u)[K - 1], const double (&un)[K - 1],
-                                                double (&c)[2 * K]) {
+__device__ __forceinline__ void recover_segment(double wi, double dwi, double xi, const double (&u)[K - 1],
+                                                const double (&un)[K - 1], double (&c)[2 * K]) {
   using C = HermiteConsts<K>;
-  constexpr int NC = 2 * K;
-  double tp[K];
-  tp[0] = 1.0;
-#pragma unroll
-  for (int n = 1; n < K; ++n) tp[n] = tp[n - 1] * Ti;
-  double xq[NC];
+  double xq[K + 1];
   xq[0] = 1.0;
 #pragma unroll
-  for (int m = 1; m < NC; ++m) xq[m] = xq[m - 1] * xi;
+  for (int m = 1; m <= K; ++m) xq[m] = xq[m - 1] * xi;
   c[0] = wi;
 #pragma unroll
   for (int n = 1; n < K; ++n) c[n] = u[n - 1] * C::INVFACT[n];
   double es[K], ee[K];
 #pragma unroll
   for (int n = 1; n < K; ++n) {
-    es[n] = tp[n] * u[n - 1];
-    ee[n] = tp[n] * un[n - 1];
+    es[n] = (n == K - 1) ? u[n - 1] : xq[K - 1 - n] * u[n - 1];
+    ee[n] = (n == K - 1) ? un[n - 1] : xq[K - 1 - n] * un[n - 1];
   }
+  const double dwx = dwi * xq[K - 1];
 #pragma unroll
   for (int m = 0; m < K; ++m) {
-    double acc = C::CE[m][0] * dwi;
+    double acc = C::CE[m][0] * dwx;
 #pragma unroll
     for (int n = 1; n < K; ++n) {
       acc = __builtin_fma(C::CS[m][n], es[n], acc);
       acc = __builtin_fma(C::CE[m][n], ee[n], acc);
     }
-    c[K + m] = acc * xq[K + m];
+    c[K + m] = acc * xq[m + 1];
   }
 }
 
@@ -705,8 +703,7 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
 #pragma unroll
     for (int r = 0; r < NU; ++r) un[r] = 0.0;
     double wn = wcur;   // w_M
-    double thi = tcur;  // t_M
-    double wq = Wv(M - 1), tq = Tv(M - 1), xq1 = sX[(M - 1) * 16 + dl];
+    double wq = Wv(M - 1), xq1 = sX[(M - 1) * 16 + dl];
     {
       const int kq = (M >= 2) ? M - 2 : 0;  // stash slot of knot M-1
       const double *zz = sZ + (size_t)kq * (NU * 64) + lane;
@@ -721,7 +718,6 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
     for (int i = M - 1; i >= 0; --i) {
       double u[NU];
       const double wi = wq;
-      const double tlo = tq;
       const double xi = xq1;
 #pragma unroll
       for (int r = 0; r < NU; ++r) {
@@ -734,7 +730,6 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
       }
       if (i >= 1) {
         wq = Wv(i - 1);
-        tq = Tv(i - 1);
         xq1 = sX[(i - 1) * 16 + dl];
         if (i >= 2) {
           const double *zz = sZ + (size_t)(i - 2) * (NU * 64) + lane;
@@ -747,10 +742,8 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
           }
         }
       }
-      const double Ti = (i == 0) ? (thi - tlo) - tlo : thi - tlo;
-      thi = tlo;
       double c[NC];
-      recover_segment<K>(wi, wn - wi, Ti, xi, u, un, c);
+      recover_segment<K>(wi, wn - wi, xi, u, un, c);
       if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
       if constexpr (NC == 8)
         store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
@@ -833,7 +826,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 
     // per-lane copies of the path: waypoints, segment lengths and their reciprocals stay in
     // registers for the backward sweep (knot loops are unrolled, so the indices are static)
-    double wreg[MAXM + 1], Treg[MAXM], xreg[MAXM], zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
+    double wreg[MAXM + 1], xreg[MAXM], zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
 
     const double t0 = lt[0];
     double tcur = lt[1];
@@ -841,9 +834,9 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     wreg[1] = lw[4];
     bool nonfinite = !(finite64(t0) & finite64(tcur) & finite64(wreg[0]) & finite64(wreg[1]));
     const double T0 = tcur - t0;
-    Treg[0] = T0 - t0;            // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
-    bool badtime = !(T0 > 0.0) | !(Treg[0] > 0.0) | (t0 < 0.0);
-    xreg[0] = rcp64(Treg[0]);
+    const double T0q = T0 - t0;   // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
+    bool badtime = !(T0 > 0.0) | !(T0q > 0.0) | (t0 < 0.0);
+    xreg[0] = rcp64(T0q);
     SW sw;
     sw.init(xreg[0], wreg[1] - wreg[0]);
 
@@ -860,9 +853,9 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
           wpre = lw[ip * 4];
         }
         nonfinite |= !finite64(tnext) | !finite64(wreg[i + 1]);
-        Treg[i] = tnext - tcur;
-        badtime |= !(Treg[i] > 0.0);
-        xreg[i] = rcp64(Treg[i]);
+        const double Ti = tnext - tcur;
+        badtime |= !(Ti > 0.0);
+        xreg[i] = rcp64(Ti);
         double G[NU][NU], z[NU];
 #ifdef MSNAP_EXPERIMENT_STORE_ONLY
 #pragma unroll
@@ -935,7 +928,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 #pragma unroll
         for (int m = 0; m < NC; ++m) c[m] = u[m % NU] + wreg[i];
 #else
-        recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], Treg[i], xreg[i], u, un, c);
+        recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], xreg[i], u, un, c);
 #endif
         if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
 #ifdef MSNAP_EXPERIMENT_LDS_TR
@@ -1072,7 +1065,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 
     // long paths keep z_i in LDS as well (one slot per lane) so the instance fits the register file
     constexpr bool kZReg = MAXH < kTwistFenceHalf;
-    double wreg[MAXH + 2], Treg[MAXH + 1], xreg[MAXH + 1], zreg[kZReg ? MAXH : 1][NU];
+    double wreg[MAXH + 2], xreg[MAXH + 1], zreg[kZReg ? MAXH : 1][NU];
     double *sZ = sTraw + kTwistDrones * tpitch + lane;      // [knot][r][64 lanes]
     // a launch of this kernel never has more than two waves per CU: the G_i blocks stay in
     // registers (overflowing into AGPRs on long paths) -- no LDS round trip on the dependent chain
@@ -1082,10 +1075,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     wreg[0] = Wown(0);
     wreg[1] = Wown(1);
     const double T0 = Town(0);
-    Treg[0] = side ? T0 : T0 - t0;   // Appendix-A quirk lives on the start side only
+    const double T0q = side ? T0 : T0 - t0;   // Appendix-A quirk lives on the start side only
     bool nonfinite = !(finite64(t0) & finite64(T0) & finite64(wreg[0]) & finite64(wreg[1]));
-    bool badtime = !(T0 > 0.0) | !(Treg[0] > 0.0) | (t0 < 0.0);
-    xreg[0] = rcp64(Treg[0]);
+    bool badtime = !(T0 > 0.0) | !(T0q > 0.0) | (t0 < 0.0);
+    xreg[0] = rcp64(T0q);
     SW sw;
     sw.init(xreg[0], wreg[1] - wreg[0]);
 #pragma unroll
@@ -1108,10 +1101,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     double xpc[SW::PM + 1], dwc;     // powers of 1/T_it and w_{it+1} - w_it of the current knot
     auto ahead = [&](int it, double (&xp)[SW::PM + 1], double &dw) {
       wreg[it + 1] = Wown(it + 1);
-      Treg[it] = Town(it);
-      nonfinite |= !finite64(Treg[it]) | !finite64(wreg[it + 1]);
-      badtime |= !(Treg[it] > 0.0);
-      xreg[it] = rcp64(Treg[it]);
+      const double Tit = Town(it);
+      nonfinite |= !finite64(Tit) | !finite64(wreg[it + 1]);
+      badtime |= !(Tit > 0.0);
+      xreg[it] = rcp64(Tit);
       SW::powers(xreg[it], xp);
       dw = wreg[it + 1] - wreg[it];
     };
@@ -1269,7 +1262,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
           const double wa = side ? wreg[it + 1] : wreg[it];
           const double wb = side ? wreg[it] : wreg[it + 1];
           double c[NC];
-          recover_segment<4>(wa, wb - wa, Treg[it], xreg[it], ua, ub, c);
+          recover_segment<4>(wa, wb - wa, xreg[it], ua, ub, c);
           if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
           const int seg = side ? M - 1 - it : it;
           // a batch this small is latency bound, not store bound: plain per-lane stores
