@@ -80,6 +80,8 @@ int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
   {
     const char *e = getenv("MSNAP_NO_TWIST");
     ctx->no_twist = (e && e[0] == '1') ? 1 : 0;
+    e = getenv("MSNAP_TWIST_MAX_DRONES");
+    if (e && atol(e) > 0) ctx->twist_max_drones = (int)atol(e);
     e = getenv("MSNAP_PIPE_CHUNK_MB");
     if (e && atol(e) > 0) ctx->pipe_chunk_bytes = (size_t)atol(e) << 20;
   }

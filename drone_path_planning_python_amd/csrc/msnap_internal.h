@@ -82,6 +82,7 @@ struct msnap_ctx {
   int grid_seg = 0;
   int grid_ready = 0;
   int no_twist = 0;        // MSNAP_NO_TWIST=1: keep small batches on the one-sided kernels (A/B timing)
+  int twist_max_drones = 0; // batches up to this size take the two-sided small-batch kernel (0: default)
   char hip_err[256] = {0};
 };
 

@@ -1291,7 +1291,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
-  if (K == 4 && M >= 3 && M <= kTwistMaxSeg && ntiles <= ctx->n_cu && !ctx->no_twist) {
+  const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones : ctx->n_cu * kDronesPerWave;
+  if (K == 4 && M >= 3 && M <= kTwistMaxSeg && N <= twist_max && !ctx->no_twist) {
     // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int mR = (M - 1) - (M - 1) / 2;
