@@ -314,7 +314,7 @@ def main():
         grid = {
             "workload": f"shared uniform time grid t_i = i*10/(M+1) (scripts/drones_pols_generator.py:44-46), "
                         f"operator prepared once, K2 fp64 MFMA GEMM per step",
-            "kernel": "msnap::grid_gemm_kernel<%d>" % (order + 1),
+            "kernel": "msnap::grid_gemm_kernel<%d, %d>" % (order + 1, M),
             "headline_shape": {"drones": args.drones, "value": args.drones / per_s, "us_per_step": per_s * 1e6,
                                "roofline_frac": bs / per_s / 1e9 / HBM_PEAK_GBS},
             "saturated": {"drones": nbig, "value": nbig / per_b, "ms_per_launch": per_b * 1e3,

@@ -65,48 +65,57 @@ __device__ __forceinline__ double dpp_quad_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-template <int NC>
+// One instance per (ncoef, segment count): tile counts are constants, so there are no per-tile
+// branches, all column tiles' MFMA chains are issued back to back (independent accumulators keep
+// the matrix pipe full) and only then exchanged and stored.
+template <int NC, int M>
 __global__ void __launch_bounds__(kWave)
 grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /* packed B fragments */,
-                 const double *__restrict__ gdur /* [M] */, const int32_t *__restrict__ gstatus, int N, int M,
-                 int nct, int nks, double *__restrict__ coef, double *__restrict__ dur,
-                 int32_t *__restrict__ status, int nrt) {
+                 const double *__restrict__ gdur /* [M] */, const int32_t *__restrict__ gstatus, int N,
+                 double *__restrict__ coef, double *__restrict__ dur, int32_t *__restrict__ status, int nrt) {
+  constexpr int m = M + 1;
+  constexpr int ncols = M * NC;
+  constexpr int NCT = (ncols + 15) / 16;
+  constexpr int NKS = (m + 3) / 4;
+  static_assert(NCT <= kGridMaxCT && NKS <= kGridMaxKS && 4 * M <= kWave, "operator does not fit the registers");
   const int lane = threadIdx.x;
   const int col = lane & 15;
   const int kq = lane >> 4;          // k offset inside a step (A/B operands), axis (D)
-  const int m = M + 1;
-  const int ncols = M * NC;
   const int grid_st = gstatus[0];
+  const bool odd = (lane & 1) != 0;
 
   // B fragments (pre-packed by pack_gop_kernel): Gop[j = 4*ks + kq][c = 16*ct + col]
-  double bf[kGridMaxCT][kGridMaxKS];
+  double bf[NCT][NKS];
 #pragma unroll
-  for (int ct = 0; ct < kGridMaxCT; ++ct) {
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-    for (int ks = 0; ks < kGridMaxKS; ++ks)
-      bf[ct][ks] = (ct < nct && ks < nks) ? gop[(size_t)(ct * kGridMaxKS + ks) * kWave + lane] : 0.0;
-  }
+    for (int ks = 0; ks < NKS; ++ks) bf[ct][ks] = gop[(size_t)(ct * kGridMaxKS + ks) * kWave + lane];
+
+  // this lane's slot of the tile's [4 drones][M] durations
+  const int r_dur = (lane < 4 * M ? lane : 0) / M;
+  const double my_dur = gdur[(lane < 4 * M ? lane : 0) - r_dur * M];
 
   // A fragments of a row tile: W[row = lane&15 -> (drone 4*rt + row>>2, axis row&3)][j = 4*ks + kq]
-  auto load_a = [&](int rt, double (&af)[kGridMaxKS]) {
+  auto load_a = [&](int rt, double (&af)[NKS]) {
     const int drow = rt * 4 + (col >> 2);
     const int dclamp = drow < N ? drow : N - 1;
     const double *wrow = wp + (size_t)dclamp * m * 4 + (col & 3);
 #pragma unroll
-    for (int ks = 0; ks < kGridMaxKS; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       const int j = 4 * ks + kq;
-      af[ks] = (ks < nks && j < m) ? wrow[(size_t)j * 4] : 0.0;
+      const double v = wrow[(size_t)(j < m ? j : m - 1) * 4];   // clamped: always a valid address
+      af[ks] = (4 * ks + 3 < m || j < m) ? v : 0.0;             // only the last k step can run past m
     }
   };
 
-  double anext[kGridMaxKS];
+  double anext[NKS];
   if ((int)blockIdx.x < nrt) load_a(blockIdx.x, anext);
   for (int rt = blockIdx.x; rt < nrt; rt += gridDim.x) {
     const int d0 = rt * 4;
-    double af[kGridMaxKS];
+    double af[NKS];
     bool nonfin = false;
 #pragma unroll
-    for (int ks = 0; ks < kGridMaxKS; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       af[ks] = anext[ks];
       nonfin = nonfin || !__builtin_isfinite(af[ks]);
     }
@@ -115,44 +124,46 @@ grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /
     // per-drone non-finite flag: rows 4*dl .. 4*dl+3 of the tile, any k
     const unsigned long long bal = __ballot(nonfin);
 
+    v4f64 acc[NCT];
 #pragma unroll
-    for (int ct = 0; ct < kGridMaxCT; ++ct) {
-      if (ct < nct) {
-        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < kGridMaxKS; ++ks) {
-          if (ks < nks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ct][ks], acc, 0, 0, 0);
-        }
-        // pair exchange (lanes l, l^1 hold adjacent columns): afterwards an even lane owns
-        // columns (c, c+1) of drones 0 and 2, an odd lane the same columns of drones 1 and 3,
-        // so every lane issues two 16-byte stores instead of four 8-byte ones
-        const bool odd = (lane & 1) != 0;
-        const double s0 = dpp_quad_f64<0xB1>(odd ? acc[0] : acc[1]);
-        const double s1 = dpp_quad_f64<0xB1>(odd ? acc[2] : acc[3]);
-        const double lo0 = odd ? s0 : acc[0], hi0 = odd ? acc[1] : s0;   // drone (odd ? 1 : 0)
-        const double lo1 = odd ? s1 : acc[2], hi1 = odd ? acc[3] : s1;   // drone (odd ? 3 : 2)
-        const int c = 16 * ct + (col & ~1);
-        const int seg = c / NC, kc = c - seg * NC;     // NC is even: a pair never straddles a segment
-        if (c < ncols) {
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int r = 2 * h + (odd ? 1 : 0);       // drone inside the tile, kq = axis
-            const int d = d0 + r;
-            // lanes of drone r as A rows: (lane & 12) == 4*r
-            const unsigned long long dm = 0x000F000F000F000FULL << (4 * r);
-            const bool bad = (grid_st != 0) || ((bal & dm) != 0ULL);
-            double2 v = h == 0 ? make_double2(lo0, hi0) : make_double2(lo1, hi1);
-            if (bad) v = make_double2(__builtin_nan(""), __builtin_nan(""));
-            if (d < N) *reinterpret_cast<double2 *>(coef + (((size_t)d * M + seg) * 4 + kq) * NC + kc) = v;
-          }
+      for (int ct = 0; ct < NCT; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], bf[ct][ks], acc[ct], 0, 0, 0);
+
+    // drones 2h + odd of the tile: bad flags once per tile
+    bool badh[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 2 * h + (odd ? 1 : 0);
+      const unsigned long long dm = 0x000F000F000F000FULL << (4 * r);   // lanes of drone r as A rows
+      badh[h] = (grid_st != 0) || ((bal & dm) != 0ULL);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      // pair exchange (lanes l, l^1 hold adjacent columns): afterwards an even lane owns
+      // columns (c, c+1) of drones 0 and 2, an odd lane the same columns of drones 1 and 3,
+      // so every lane issues two 16-byte stores instead of four 8-byte ones
+      const double s0 = dpp_quad_f64<0xB1>(odd ? acc[ct][0] : acc[ct][1]);
+      const double s1 = dpp_quad_f64<0xB1>(odd ? acc[ct][2] : acc[ct][3]);
+      const double lo0 = odd ? s0 : acc[ct][0], hi0 = odd ? acc[ct][1] : s0;   // drone (odd ? 1 : 0)
+      const double lo1 = odd ? s1 : acc[ct][2], hi1 = odd ? acc[ct][3] : s1;   // drone (odd ? 3 : 2)
+      const int c = 16 * ct + (col & ~1);
+      const int seg = c / NC, kc = c - seg * NC;     // NC is even: a pair never straddles a segment
+      if (16 * ct + 15 < ncols || c < ncols) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int d = d0 + 2 * h + (odd ? 1 : 0);   // kq = axis
+          double2 v = h == 0 ? make_double2(lo0, hi0) : make_double2(lo1, hi1);
+          if (badh[h]) v = make_double2(__builtin_nan(""), __builtin_nan(""));
+          if (d < N) *reinterpret_cast<double2 *>(coef + (((size_t)d * M + seg) * 4 + kq) * NC + kc) = v;
         }
       }
     }
     // durations and status of the 4 drones
-    for (int e = lane; e < 4 * M; e += kWave) {
-      const int r = e / M;
-      if (d0 + r < N) dur[(size_t)d0 * M + e] = gdur[e - r * M];
-    }
+    if (lane < 4 * M && d0 + r_dur < N) dur[(size_t)d0 * M + lane] = my_dur;
     if (lane < 4 && d0 + lane < N) {
       const unsigned long long dm = 0x000F000F000F000FULL << (4 * lane);
       status[d0 + lane] = (bal & dm) ? MSNAP_ST_NONFINITE : grid_st;
@@ -205,19 +216,32 @@ int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *co
     return launch_solve(ctx, n_drones, M, wp, (const double *)ctx->grid_t.p, 1, coef, dur, status);
   }
   const int nc = ctx->order + 1;
-  const int nct = (M * nc + 15) / 16;
-  const int nks = (M + 1 + 3) / 4;
   const int nrt = (n_drones + 3) / 4;
   int grid = ctx->n_cu * 8;
   if (grid > nrt) grid = nrt;
-  if (nc == 8)
-    hipLaunchKernelGGL((grid_gemm_kernel<8>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,
-                       (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,
-                       (const int32_t *)ctx->grid_status.p, n_drones, M, nct, nks, coef, dur, status, nrt);
-  else
-    hipLaunchKernelGGL((grid_gemm_kernel<10>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,
-                       (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,
-                       (const int32_t *)ctx->grid_status.p, n_drones, M, nct, nks, coef, dur, status, nrt);
+#define MSNAP_GRID_CASE(NCV, MM)                                                                       \
+  case MM:                                                                                             \
+    hipLaunchKernelGGL((grid_gemm_kernel<NCV, MM>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,       \
+                       (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,              \
+                       (const int32_t *)ctx->grid_status.p, n_drones, coef, dur, status, nrt);         \
+    break;
+  if (nc == 8) {
+    switch (M) {   // grid_gemm_supported: M <= 15
+      MSNAP_GRID_CASE(8, 1) MSNAP_GRID_CASE(8, 2) MSNAP_GRID_CASE(8, 3) MSNAP_GRID_CASE(8, 4)
+      MSNAP_GRID_CASE(8, 5) MSNAP_GRID_CASE(8, 6) MSNAP_GRID_CASE(8, 7) MSNAP_GRID_CASE(8, 8)
+      MSNAP_GRID_CASE(8, 9) MSNAP_GRID_CASE(8, 10) MSNAP_GRID_CASE(8, 11) MSNAP_GRID_CASE(8, 12)
+      MSNAP_GRID_CASE(8, 13) MSNAP_GRID_CASE(8, 14) MSNAP_GRID_CASE(8, 15)
+      default: return MSNAP_EINVAL;
+    }
+  } else {
+    switch (M) {   // grid_gemm_supported: M <= 12
+      MSNAP_GRID_CASE(10, 1) MSNAP_GRID_CASE(10, 2) MSNAP_GRID_CASE(10, 3) MSNAP_GRID_CASE(10, 4)
+      MSNAP_GRID_CASE(10, 5) MSNAP_GRID_CASE(10, 6) MSNAP_GRID_CASE(10, 7) MSNAP_GRID_CASE(10, 8)
+      MSNAP_GRID_CASE(10, 9) MSNAP_GRID_CASE(10, 10) MSNAP_GRID_CASE(10, 11) MSNAP_GRID_CASE(10, 12)
+      default: return MSNAP_EINVAL;
+    }
+  }
+#undef MSNAP_GRID_CASE
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
