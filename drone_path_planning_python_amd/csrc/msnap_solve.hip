@@ -137,20 +137,10 @@ struct Sweep {
     }
   }
 
-  // the recurrence proper: S_i = D_i - O_{i-1}^T G_{i-1}, LDL^T, G_i = S_i^-1 O_i, z_i = S_i^-1 y_i,
-  // and the Schur terms carried to knot i+1.  Returns false if a pivot is not positive and finite.
-  __device__ __forceinline__ bool chain(const Knot &k, double (&G)[NU][NU], double (&z)[NU]) {
-    double S[NS], y[NU];
-#pragma unroll
-    for (int n = 0; n < NU; ++n) {
-#pragma unroll
-      for (int m = 0; m <= n; ++m) S[sidx(n, m)] = k.D[sidx(n, m)] - OtG[sidx(n, m)];
-      y[n] = -k.yb[n] - Otz[n];
-    }
-
-    // LDL^T of S; S's strict lower part holds w_rp = L_rp d_p until scaled
+  // LDL^T of the symmetric block S in place (strict lower part -> L, dinv -> 1/d); returns true
+  // if a pivot is not positive and finite
+  __device__ __forceinline__ static bool ldl_factor(double (&S)[NS], double (&dinv)[NU]) {
     bool bad = false;
-    double dinv[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double dj = S[sidx(j, j)];
@@ -163,13 +153,43 @@ struct Sweep {
         double v = S[sidx(r, j)];
 #pragma unroll
         for (int p = 0; p < j; ++p) v = __builtin_fma(-S[sidx(r, p)] * dinv[p], S[sidx(j, p)], v);
-        S[sidx(r, j)] = v;
+        S[sidx(r, j)] = v;     // w_rj = L_rj d_j until scaled below
       }
     }
 #pragma unroll
     for (int r = 1; r < NU; ++r)
 #pragma unroll
       for (int p = 0; p < r; ++p) S[sidx(r, p)] *= dinv[p];
+    return bad;
+  }
+
+  // v <- S^-1 v with the factor of ldl_factor
+  __device__ __forceinline__ static void ldl_solve(const double (&S)[NS], const double (&dinv)[NU], double (&v)[NU]) {
+#pragma unroll
+    for (int r = 1; r < NU; ++r)
+#pragma unroll
+      for (int p = 0; p < r; ++p) v[r] = __builtin_fma(-S[sidx(r, p)], v[p], v[r]);
+#pragma unroll
+    for (int r = 0; r < NU; ++r) v[r] *= dinv[r];
+#pragma unroll
+    for (int r = NU - 2; r >= 0; --r)
+#pragma unroll
+      for (int p = r + 1; p < NU; ++p) v[r] = __builtin_fma(-S[sidx(p, r)], v[p], v[r]);
+  }
+
+  // the recurrence proper: S_i = D_i - O_{i-1}^T G_{i-1}, LDL^T, G_i = S_i^-1 O_i, z_i = S_i^-1 y_i,
+  // and the Schur terms carried to knot i+1.  Returns false if a pivot is not positive and finite.
+  __device__ __forceinline__ bool chain(const Knot &k, double (&G)[NU][NU], double (&z)[NU]) {
+    double S[NS], y[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n) {
+#pragma unroll
+      for (int m = 0; m <= n; ++m) S[sidx(n, m)] = k.D[sidx(n, m)] - OtG[sidx(n, m)];
+      y[n] = -k.yb[n] - Otz[n];
+    }
+
+    double dinv[NU];
+    const bool bad = ldl_factor(S, dinv);
 
     // NU + 1 solves with the factor: columns of O_i, then y
 #pragma unroll
@@ -177,16 +197,7 @@ struct Sweep {
       double v[NU];
 #pragma unroll
       for (int r = 0; r < NU; ++r) v[r] = (c < NU) ? k.O[r][c < NU ? c : 0] : y[r];
-#pragma unroll
-      for (int r = 1; r < NU; ++r)
-#pragma unroll
-        for (int p = 0; p < r; ++p) v[r] = __builtin_fma(-S[sidx(r, p)], v[p], v[r]);
-#pragma unroll
-      for (int r = 0; r < NU; ++r) v[r] *= dinv[r];
-#pragma unroll
-      for (int r = NU - 2; r >= 0; --r)
-#pragma unroll
-        for (int p = r + 1; p < NU; ++p) v[r] = __builtin_fma(-S[sidx(p, r)], v[p], v[r]);
+      ldl_solve(S, dinv, v);
 #pragma unroll
       for (int r = 0; r < NU; ++r) {
         if (c < NU) G[r][c < NU ? c : 0] = v[r];
@@ -948,16 +959,17 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 }
 
 // ------------------------------------------------------------------------------------
-// small-batch variant (order 7, 3 <= n_seg <= 2*MAXH): two-sided ("twisted") sweep.
+// small-batch variant (2 <= n_seg <= kTwistMaxSeg): two-sided ("twisted") sweep.
 // With few drones a launch is one wavefront's dependent chain, so the chain is halved:
 // lane = 8*drone + 4*side + axis.  Side 0 sweeps the knots from the start of the path,
 // side 1 runs THE SAME recurrence on the time-reversed path (p'(s) = p(T_total - s):
-// waypoints and segment lengths reversed, odd derivatives change sign), both stop at the
-// middle segment, exchange their last (G, z) through one cross-lane swap, solve the
-// 2-knot coupling
-//     u_a = z_a - G_a u_b ,   D u_b = z_b - G_b D u_a ,   D = diag(-1, +1, -1)
-// and back-substitute outwards.  Side 1 converts its pieces back with a Taylor shift by
-// the segment length and a sign flip of the odd coefficients (p(t) = q(T - t)).
+// waypoints and segment lengths reversed, odd derivatives change sign, D = diag(-1,+1,-1,..)).
+// Both stop one knot short of the MEETING knot in the middle.  What each side carries towards
+// it -- the end-side block of its last segment and its Schur terms -- adds up (the other
+// side's part conjugated by D) to the meeting knot's own symmetric positive definite block, so
+// the merge is one cross-lane swap and one more LDL^T step; then both sides back-substitute
+// outwards.  Side 1 obtains forward-time coefficients by recovering each piece with its two
+// end states swapped and the odd derivatives negated (p(t) = q(T - t)).
 // ------------------------------------------------------------------------------------
 constexpr int kTwistDrones = 8;
 constexpr int kTwistFenceHalf = 9;   // instances with this many knots per side fence the scheduler per knot
@@ -977,17 +989,20 @@ __device__ unsigned long long g_timeline[1024 * 32];
 #define MSNAP_TL(k) do { } while (0)
 #endif
 
-// One instance per segment count M (MAXH = knots on the longer side): every loop bound is a
-// constant, so the whole solve is straight-line code that the scheduler interleaves across knots
+// One instance per (order, segment count M); MAXH = knots of the longer side.  Every loop bound is
+// a constant, so the whole solve is straight-line code that the scheduler interleaves across knots
 // (a run-time M costs block boundaries with dozens of register copies each: 6.2 vs 5.3 us at M = 10).
-template <int MAXH, int M>
+template <int K, int MAXH, int M>
 __global__ void __launch_bounds__(kWave)
 solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
                    int N, double *__restrict__ coef, double *__restrict__ dur,
                    int32_t *__restrict__ status, int ntiles) {
-  using SW = Sweep<4>;
-  constexpr int NU = 3, NC = 8;
-  static_assert(M >= 3 && MAXH == (M - 1) - (M - 1) / 2, "MAXH is the knot count of the longer side");
+  using SW = Sweep<K>;
+  constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS;
+  // M - 1 interior knots = nL (side 0) + the meeting knot + nR (side 1), nL <= nR <= nL + 1
+  constexpr int nL = (M - 2) / 2, nR = (M - 2) - nL;
+  static_assert(M >= 2 && MAXH == nR, "MAXH is the knot count of the longer side");
+  constexpr int HA = MAXH > 0 ? MAXH : 1;     // array extent (M = 2 has no side knots)
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
 
@@ -995,13 +1010,15 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   const int a = lane & 3;
   const int side = (lane >> 2) & 1;
   const int dl = lane >> 3;           // drone inside the tile
-  const int wpitch = (M + 1) * 4;
-  const int tpitch = M + 1;
-  const int mL = (M - 1) / 2, mR = (M - 1) - mL;      // knots per side, mL <= mR
-  const int mside = side ? mR : mL;
-  const int mmax = mR;
+  constexpr int wpitch = (M + 1) * 4;
+  constexpr int tpitch = M + 1;
+  const int mside = side ? nR : nL;
   double *sWraw = lds;
   double *sTraw = sWraw + kTwistDrones * wpitch;
+  // D = diag(-1, +1, -1, ...): derivative r+1 of the time-reversed path
+  double dsg[NU];
+#pragma unroll
+  for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #ifdef MSNAP_EXPERIMENT_TIMELINE
@@ -1021,7 +1038,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       const int wcnt = nvalid * wpitch / 2;
       const double *tsrc = shared_times ? tt : tt + (size_t)tile * kTwistDrones * tpitch;
       const int tcnt = shared_times ? tpitch : nvalid * tpitch;
-      constexpr int UW = (2 * MAXH + 2 + 3) / 4, UT = (2 * MAXH + 2 + 7) / 8;   // 8*(M+1)*2/64, 8*(M+1)/64
+      constexpr int UW = (kTwistDrones * wpitch / 2 + kWave - 1) / kWave;
+      constexpr int UT = (kTwistDrones * tpitch + kWave - 1) / kWave;
       double2 vw[UW];
       double vt[UT];
 #pragma unroll
@@ -1063,14 +1081,13 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       return lt[j + 1] - lt[j];
     };
 
-    // long paths keep z_i in LDS as well (one slot per lane) so the instance fits the register file
-    constexpr bool kZReg = MAXH < kTwistFenceHalf;
-    double wreg[MAXH + 2], xreg[MAXH + 1], zreg[kZReg ? MAXH : 1][NU];
+    // long paths keep z_i in LDS (one slot per lane) so the instance fits the register file
+    constexpr bool kZReg = MAXH * NU < 3 * kTwistFenceHalf;
+    double wreg[HA + 2], xreg[HA + 1], zreg[kZReg ? HA : 1][NU];
     double *sZ = sTraw + kTwistDrones * tpitch + lane;      // [knot][r][64 lanes]
     // a launch of this kernel never has more than two waves per CU: the G_i blocks stay in
     // registers (overflowing into AGPRs on long paths) -- no LDS round trip on the dependent chain
-    double Greg[MAXH][NU][NU];
-    double Gl[NU][NU], zl[NU];
+    double Greg[HA][NU][NU];
     const double t0 = lt[0];
     wreg[0] = Wown(0);
     wreg[1] = Wown(1);
@@ -1081,24 +1098,13 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     xreg[0] = rcp64(T0q);
     SW sw;
     sw.init(xreg[0], wreg[1] - wreg[0]);
-#pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      zl[r] = 0.0;
-#pragma unroll
-      for (int c = 0; c < NU; ++c) Gl[r][c] = 0.0;
-    }
 
-    // A lone wave is bound by instruction issue and dependent latency, so each knot's geometry
-    // (1/T, its powers, D, O, the right-hand side: independent of the recurrence) is computed one
-    // knot AHEAD, inside the same basic block as the previous knot's recurrence, where the
-    // scheduler can fill the recurrence's latency bubbles with it.  All lanes run all mmax steps
-    // (side 0 may own one knot less: its extra step works on valid data and is not committed).
     // Per knot, the long dependent prefix that does not involve the recurrence -- inputs from LDS,
     // T, 1/T (reciprocal + Newton), its powers -- is prepared one knot AHEAD, inside the same
     // basic block as the previous knot's recurrence, where it fills that chain's latency bubbles.
-    // All lanes run all mmax steps (side 0 may own one knot less: its extra step works on valid
-    // data and is not committed).
-    double xpc[SW::PM + 1], dwc;     // powers of 1/T_it and w_{it+1} - w_it of the current knot
+    // All lanes run all nR steps; when side 0 owns one knot less its extra step works on valid
+    // data and its effect on the carried state is undone.
+    double xpc[SW::PM + 1], dwc = 0.0;     // powers of 1/T_it and w_{it+1} - w_it of the current knot
     auto ahead = [&](int it, double (&xp)[SW::PM + 1], double &dw) {
       wreg[it + 1] = Wown(it + 1);
       const double Tit = Town(it);
@@ -1108,59 +1114,75 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       SW::powers(xreg[it], xp);
       dw = wreg[it + 1] - wreg[it];
     };
-    ahead(1, xpc, dwc);              // M >= 3: knot 1 and segment 1 exist on both sides
+    if (MAXH >= 1) ahead(1, xpc, dwc);
     bool singular = false;
-    auto commit = [&](int it, const double (&G)[NU][NU], const double (&z)[NU]) {
+    auto knot_step = [&](int it) {
+      double G[NU][NU], z[NU];
+      typename SW::Knot k;
+      SW::knot_geom_xp(xpc, dwc, sw.E, sw.re, k);
+      const bool ok = sw.chain(k, G, z);
+      singular |= !ok & (it <= mside);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) sw.E[e] = k.E[e];
 #pragma unroll
       for (int r = 0; r < NU; ++r) {
+        sw.re[r] = k.re[r];
         if constexpr (kZReg) zreg[it - 1][r] = z[r];
         else sZ[((it - 1) * NU + r) * kWave] = z[r];
 #pragma unroll
         for (int c = 0; c < NU; ++c) Greg[it - 1][r][c] = G[r][c];
       }
     };
-    auto knot_step = [&](int it, double (&G)[NU][NU], double (&z)[NU]) {
-      typename SW::Knot k;
-      SW::knot_geom_xp(xpc, dwc, sw.E, sw.re, k);
-      const bool ok = sw.chain(k, G, z);
-      singular |= !ok & (it <= mside);
-#pragma unroll
-      for (int e = 0; e < SW::NS; ++e) sw.E[e] = k.E[e];
-#pragma unroll
-      for (int r = 0; r < NU; ++r) sw.re[r] = k.re[r];
-      commit(it, G, z);
-    };
 #pragma unroll
     for (int it = 1; it <= MAXH; ++it) {
-      if (it < mmax) {             // wave-uniform: knot it, and the prefix of knot it+1
-        double G[NU][NU], z[NU], xpn[SW::PM + 1], dwn = 0.0;
-        if (it < MAXH) ahead(it + 1, xpn, dwn);
-        knot_step(it, G, z);
-        if (it < MAXH) {
-          dwc = dwn;
+      if (it < MAXH) {             // knot it, and the prefix of knot it+1
+        double xpn[SW::PM + 1], dwn;
+        ahead(it + 1, xpn, dwn);
+        knot_step(it);
+        dwc = dwn;
 #pragma unroll
-          for (int q = 0; q <= SW::PM; ++q) xpc[q] = xpn[q];
-        }
+        for (int q = 0; q <= SW::PM; ++q) xpc[q] = xpn[q];
         // long paths: keep the scheduler from hoisting several knots' inputs at once (register
         // pressure beyond the 512-entry file would spill to scratch)
-        if constexpr (MAXH >= kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
-      } else if (it == mmax) {     // last knot, then pick each side's own last knot
-        double G[NU][NU], z[NU];
-        knot_step(it, G, z);
-        const bool own = mside == mmax;    // else this side stopped one knot earlier
+        if constexpr (MAXH * NU >= 3 * kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
+      } else if (nL == nR) {       // last knot, owned by both sides
+        knot_step(it);
+      } else {                     // last knot of side 1 only: side 0 keeps its carried state
+        double E0[NS], G0[NS], r0[NU], z0[NU];
 #pragma unroll
-        for (int r = 0; r < NU; ++r) {
-          double zp;
-          if constexpr (kZReg) zp = zreg[it >= 2 ? it - 2 : 0][r];
-          else zp = (it >= 2) ? sZ[((it - 2) * NU + r) * kWave] : 0.0;
-          zl[r] = own ? z[r] : zp;
+        for (int e = 0; e < NS; ++e) { E0[e] = sw.E[e]; G0[e] = sw.OtG[e]; }
 #pragma unroll
-          for (int c = 0; c < NU; ++c) Gl[r][c] = own ? G[r][c] : Greg[it >= 2 ? it - 2 : 0][r][c];
-        }
+        for (int r = 0; r < NU; ++r) { r0[r] = sw.re[r]; z0[r] = sw.Otz[r]; }
+        knot_step(it);
+#pragma unroll
+        for (int e = 0; e < NS; ++e) { sw.E[e] = side ? sw.E[e] : E0[e]; sw.OtG[e] = side ? sw.OtG[e] : G0[e]; }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) { sw.re[r] = side ? sw.re[r] : r0[r]; sw.Otz[r] = side ? sw.Otz[r] : z0[r]; }
       }
     }
 
     MSNAP_TL(2);
+    // ---- the meeting knot: both sides' carried blocks add up to ONE symmetric positive definite
+    // system,  S = (E - O^T G)_own + D (E - O^T G)_other D ,  y = -(re + O^T z)_own - D (re + O^T z)_other
+    // (each side in its own orientation; D conjugates the other side's blocks).  One cross-lane
+    // swap, then the same LDL^T as every other knot.
+    double Sm[NS], um[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      const double q = sw.re[r] + sw.Otz[r];
+      um[r] = -q - dsg[r] * __shfl_xor(q, 4);
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const double p = sw.E[sidx(r, c)] - sw.OtG[sidx(r, c)];
+        Sm[sidx(r, c)] = p + (dsg[r] * dsg[c]) * __shfl_xor(p, 4);
+      }
+    }
+    {
+      double dinv[NU];
+      singular |= SW::ldl_factor(Sm, dinv);
+      SW::ldl_solve(Sm, dinv, um);
+    }
+
     // per-drone status over the 8 lanes (2 sides x 4 axes): wave ballots, no cross-lane round trips
     const int gsh = lane & ~7;
     const bool f_nonfinite = ((__ballot(nonfinite) >> gsh) & 0xFFull) != 0;
@@ -1170,118 +1192,67 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     if (live && (lane & 7) == 0) status[d] = st;
     const bool bad = st != 0;
 
-    // ---- merge: swap (G, z) of the two sides' last knots, solve the 2-knot coupling ----
-    double Go[NU][NU], zo[NU];
-#pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      zo[r] = __shfl_xor(zl[r], 4);
-#pragma unroll
-      for (int c = 0; c < NU; ++c) Go[r][c] = __shfl_xor(Gl[r][c], 4);
-    }
-    const double dsg[NU] = {-1.0, 1.0, -1.0};
-    double A[NU][NU], rhs[NU];
-#pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      double rv = zl[r];
-#pragma unroll
-      for (int q = 0; q < NU; ++q) rv = __builtin_fma(-Gl[r][q] * dsg[q], zo[q], rv);
-      rhs[r] = rv;
-#pragma unroll
-      for (int c = 0; c < NU; ++c) {
-        double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = 0; q < NU; ++q) v = __builtin_fma(-Gl[r][q] * dsg[q], Go[q][c] * dsg[c], v);
-        A[r][c] = v;
-      }
-    }
-    // 3x3 solve by cofactors (A = S_a^-1 x Schur complement of an SPD system: well conditioned)
-    const double c00 = A[1][1] * A[2][2] - A[1][2] * A[2][1];
-    const double c01 = A[1][2] * A[2][0] - A[1][0] * A[2][2];
-    const double c02 = A[1][0] * A[2][1] - A[1][1] * A[2][0];
-    const double det = A[0][0] * c00 + A[0][1] * c01 + A[0][2] * c02;
-    const double idet = rcp64(det);
-    const double c10 = A[0][2] * A[2][1] - A[0][1] * A[2][2];
-    const double c11 = A[0][0] * A[2][2] - A[0][2] * A[2][0];
-    const double c12 = A[0][1] * A[2][0] - A[0][0] * A[2][1];
-    const double c20 = A[0][1] * A[1][2] - A[0][2] * A[1][1];
-    const double c21 = A[0][2] * A[1][0] - A[0][0] * A[1][2];
-    const double c22 = A[0][0] * A[1][1] - A[0][1] * A[1][0];
-    double ulast[NU], unext[NU];
-    ulast[0] = (c00 * rhs[0] + c10 * rhs[1] + c20 * rhs[2]) * idet;
-    ulast[1] = (c01 * rhs[0] + c11 * rhs[1] + c21 * rhs[2]) * idet;
-    ulast[2] = (c02 * rhs[0] + c12 * rhs[1] + c22 * rhs[2]) * idet;
-#pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      double v = zo[r];
-#pragma unroll
-      for (int c = 0; c < NU; ++c) v = __builtin_fma(-Go[r][c] * dsg[c], ulast[c], v);
-      unext[r] = dsg[r] * v;
-    }
-
     MSNAP_TL(3);
-    // ---- outward back-substitution + recovery; side 0 also owns the middle segment ----
+    // ---- outward back-substitution + recovery: side s owns its segments 0 .. mside ----
     // A failed drone's outputs are NaN: poison what every coefficient is computed from once
-    // (waypoints -> c0 and the end-side block, knot states -> c1..c3) instead of selecting per piece.
+    // (waypoints -> c0 and the end-side block, knot states -> c1..) instead of selecting per piece.
     const double qnan = __builtin_nan("");
     const double zero_or_nan = bad ? qnan : 0.0;
 #pragma unroll
     for (int i = 0; i < MAXH + 2; ++i) wreg[i] = bad ? qnan : wreg[i];
-    const int top = side ? mside - 1 : mside;
     double un[NU];
 #pragma unroll
-    for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : (side ? ulast[r] : unext[r]);
+    for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : um[r];
 #pragma unroll
     for (int it = MAXH; it >= 0; --it) {
-      if (it <= mmax) {          // wave-uniform (top <= mmax)
-        if (it <= top) {         // per side; the 4 axis lanes of a quad agree
-          double u[NU];
-          if (it >= 1) {
-            // side 0 at its last knot: this is the merge's first equation, u_a = z_a - G_a u_b
-#pragma unroll
-            for (int r = 0; r < NU; ++r) {
-              double v;
-              if constexpr (kZReg) v = zreg[it >= 1 ? it - 1 : 0][r];
-              else v = sZ[((it >= 1 ? it - 1 : 0) * NU + r) * kWave];
-#pragma unroll
-              for (int c = 0; c < NU; ++c) v = __builtin_fma(-Greg[it >= 1 ? it - 1 : 0][r][c], un[c], v);
-              u[r] = v;
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < NU; ++r) u[r] = zero_or_nan;
-          }
-          // Side 1 holds the piece in reversed time, q(s) with p(t) = q(T - t).  Its endpoint states in
-          // forward time are the reversed ones with the odd derivatives negated, so the forward
-          // coefficients come from the same recovery with the two ends swapped -- no Taylor shift.
-          double ua[NU], ub[NU];
+      if (it <= nL || side) {    // only side 1 owns segment nR when nL < nR
+        double u[NU];
+        if (it >= 1) {
 #pragma unroll
           for (int r = 0; r < NU; ++r) {
-            ua[r] = side ? dsg[r] * un[r] : u[r];      // state at the forward start of the piece
-            ub[r] = side ? dsg[r] * u[r] : un[r];      // state at its forward end
-          }
-          const double wa = side ? wreg[it + 1] : wreg[it];
-          const double wb = side ? wreg[it] : wreg[it + 1];
-          double c[NC];
-          recover_segment<4>(wa, wb - wa, xreg[it], ua, ub, c);
-          if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-          const int seg = side ? M - 1 - it : it;
-          // a batch this small is latency bound, not store bound: plain per-lane stores
-          if (live) {
-            double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
+            double v;
+            if constexpr (kZReg) v = zreg[it >= 1 ? it - 1 : 0][r];
+            else v = sZ[((it >= 1 ? it - 1 : 0) * NU + r) * kWave];
 #pragma unroll
-            for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
+            for (int c = 0; c < NU; ++c) v = __builtin_fma(-Greg[it >= 1 ? it - 1 : 0][r][c], un[c], v);
+            u[r] = v;
           }
+        } else {
 #pragma unroll
-          for (int r = 0; r < NU; ++r) un[r] = u[r];
+          for (int r = 0; r < NU; ++r) u[r] = zero_or_nan;
         }
-        if constexpr (MAXH >= kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
+        // Side 1 holds the piece in reversed time, q(s) with p(t) = q(T - t).  Its endpoint states in
+        // forward time are the reversed ones with the odd derivatives negated, so the forward
+        // coefficients come from the same recovery with the two ends swapped -- no Taylor shift.
+        double ua[NU], ub[NU];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+          ua[r] = side ? dsg[r] * un[r] : u[r];      // state at the forward start of the piece
+          ub[r] = side ? dsg[r] * u[r] : un[r];      // state at its forward end
+        }
+        const double wa = side ? wreg[it + 1] : wreg[it];
+        const double wb = side ? wreg[it] : wreg[it + 1];
+        double c[NC];
+        recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
+        if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+        const int seg = side ? M - 1 - it : it;
+        // a batch this small is latency bound, not store bound: plain per-lane stores
+        if (live) {
+          double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
+#pragma unroll
+          for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
+        }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) un[r] = u[r];
       }
+      if constexpr (MAXH * NU >= 3 * kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
     }
     MSNAP_TL(4);
   }
 }
 
-constexpr int kTwistMaxSeg = 24;   // twisted variant: one instance per n_seg in 3..24
+constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
+constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
@@ -1292,25 +1263,34 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones : ctx->n_cu * kDronesPerWave;
-  if (K == 4 && M >= 3 && M <= kTwistMaxSeg && N <= twist_max && !ctx->no_twist) {
+  if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {
     // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
-    const int mR = (M - 1) - (M - 1) / 2;
-    // inputs + z stash (64 lanes x 3 per knot; used by the long-path instances only)
-    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)64 * 3 * mR) * sizeof(double);
+    const int nR = (M - 2) - (M - 2) / 2;
+    // inputs + z stash (64 lanes x NU per knot; used by the long-path instances only)
+    const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)64 * (K - 1) * nR) * sizeof(double);
 #define MSNAP_TWIST_EXACT(MM)                                                                          \
   case MM:                                                                                             \
-    hipLaunchKernelGGL((solve_kernel_twist<(MM - 1) - (MM - 1) / 2, MM>), dim3(nt8), dim3(kWave),      \
+    hipLaunchKernelGGL((solve_kernel_twist<K, (MM - 2) - (MM - 2) / 2, MM>), dim3(nt8), dim3(kWave),   \
                        lds_bytes, ctx->stream, wp, t, shared, N, coef, dur, status, nt8);             \
     break;
-    switch (M) {   // 3 <= M <= kTwistMaxSeg
-      MSNAP_TWIST_EXACT(3) MSNAP_TWIST_EXACT(4) MSNAP_TWIST_EXACT(5) MSNAP_TWIST_EXACT(6)
-      MSNAP_TWIST_EXACT(7) MSNAP_TWIST_EXACT(8) MSNAP_TWIST_EXACT(9) MSNAP_TWIST_EXACT(10)
-      MSNAP_TWIST_EXACT(11) MSNAP_TWIST_EXACT(12) MSNAP_TWIST_EXACT(13) MSNAP_TWIST_EXACT(14)
-      MSNAP_TWIST_EXACT(15) MSNAP_TWIST_EXACT(16) MSNAP_TWIST_EXACT(17) MSNAP_TWIST_EXACT(18)
-      MSNAP_TWIST_EXACT(19) MSNAP_TWIST_EXACT(20) MSNAP_TWIST_EXACT(21) MSNAP_TWIST_EXACT(22)
-      MSNAP_TWIST_EXACT(23) MSNAP_TWIST_EXACT(24)
-      default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+    if constexpr (K == 4) {
+      switch (M) {   // 2 <= M <= kTwistMaxSeg
+        MSNAP_TWIST_EXACT(2) MSNAP_TWIST_EXACT(3) MSNAP_TWIST_EXACT(4) MSNAP_TWIST_EXACT(5)
+        MSNAP_TWIST_EXACT(6) MSNAP_TWIST_EXACT(7) MSNAP_TWIST_EXACT(8) MSNAP_TWIST_EXACT(9)
+        MSNAP_TWIST_EXACT(10) MSNAP_TWIST_EXACT(11) MSNAP_TWIST_EXACT(12) MSNAP_TWIST_EXACT(13)
+        MSNAP_TWIST_EXACT(14) MSNAP_TWIST_EXACT(15) MSNAP_TWIST_EXACT(16) MSNAP_TWIST_EXACT(17)
+        MSNAP_TWIST_EXACT(18) MSNAP_TWIST_EXACT(19) MSNAP_TWIST_EXACT(20) MSNAP_TWIST_EXACT(21)
+        MSNAP_TWIST_EXACT(22) MSNAP_TWIST_EXACT(23) MSNAP_TWIST_EXACT(24)
+        default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+      }
+    } else {
+      switch (M) {   // 2 <= M <= kTwistMaxSeg9
+        MSNAP_TWIST_EXACT(2) MSNAP_TWIST_EXACT(3) MSNAP_TWIST_EXACT(4) MSNAP_TWIST_EXACT(5)
+        MSNAP_TWIST_EXACT(6) MSNAP_TWIST_EXACT(7) MSNAP_TWIST_EXACT(8) MSNAP_TWIST_EXACT(9)
+        MSNAP_TWIST_EXACT(10) MSNAP_TWIST_EXACT(11) MSNAP_TWIST_EXACT(12)
+        default: return MSNAP_EINVAL;
+      }
     }
 #undef MSNAP_TWIST_EXACT
     MSNAP_HIP(ctx, hipGetLastError());
