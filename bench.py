@@ -64,8 +64,7 @@ def pmc_traffic(n_drones: int, n_seg: int, order: int):
 def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
     """Which K1 variant libmsnap launches (mirror of launch_solve_k in csrc/msnap_solve.hip)."""
     k = (order + 1) // 2
-    ntiles = (n_drones + 15) // 16
-    if 2 <= n_seg <= (24 if k == 4 else 12) and ntiles <= n_cu:
+    if 2 <= n_seg <= (24 if k == 4 else 12) and n_drones <= n_cu * 32:
         return "msnap::solve_kernel_twist<%d, %d, %d>" % (k, (n_seg - 2) - (n_seg - 2) // 2, n_seg)
     if n_seg <= 20:
         return "msnap::solve_kernel_reg<%d, %d>" % (k, 10 if n_seg <= 10 else 20)

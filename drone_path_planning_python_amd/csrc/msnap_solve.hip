@@ -1262,9 +1262,10 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
                           double *coef, double *dur, int32_t *status) {
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
-  const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones : ctx->n_cu * kDronesPerWave;
+  // up to one 8-drone wavefront per SIMD the two-sided kernel wins (measured crossover 8-10 k drones on 256 CUs)
+  const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones : ctx->n_cu * 4 * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {
-    // small batch: fewer than one 16-drone wavefront per CU -- halve the dependent chain instead
+    // small batch: at most one wavefront per SIMD -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
     const int nR = (M - 2) - (M - 2) / 2;
     // inputs + z stash (64 lanes x NU per knot; used by the long-path instances only)

@@ -323,28 +323,63 @@ def test_grid_status_and_errors():
 # ---------------------------------------------------------------------------
 # small-batch two-sided ("twisted") kernel vs the one-sided kernels
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("m", [3, 4, 5, 9, 10, 11, 12])
-def test_twisted_and_one_sided_kernels_agree(m, monkeypatch):
-    """Batches below one wavefront per CU take solve_kernel_twist; MSNAP_NO_TWIST=1 keeps
-    them on the one-sided kernels.  Both must match the oracle, and each other to ~1e-12."""
+@pytest.mark.parametrize("order,m", [(7, m) for m in (2, 3, 4, 5, 9, 10, 11, 12, 13, 17, 20, 24)] +
+                         [(9, m) for m in (2, 3, 6, 9, 10, 12)])
+def test_twisted_and_one_sided_kernels_agree(order, m, monkeypatch):
+    """Small batches take solve_kernel_twist (one instance per segment count); MSNAP_NO_TWIST=1
+    keeps them on the one-sided kernels (register-resident up to 20 segments, LDS stash above).
+    Both must match the oracle, and each other to ~1e-11."""
     from drone_path_planning_python_amd import Context
     from drone_path_planning_python_amd.synthetic import swarm
     wp, t = swarm(500 + m, 37, m)
     t[5] += 0.3                     # one drone with t[0] != 0 (quirk on the start side)
-    with Context(order=7, max_segments=64) as ctx:
+    with Context(order=order, max_segments=64) as ctx:
         c_tw, d_tw, s_tw = ctx.solve_batch(wp, t)
     monkeypatch.setenv("MSNAP_NO_TWIST", "1")
-    with Context(order=7, max_segments=64) as ctx:
+    with Context(order=order, max_segments=64) as ctx:
         c_os, d_os, s_os = ctx.solve_batch(wp, t)
     assert (s_tw == 0).all() and (s_os == 0).all()
     import msnap_oracle as O
-    ref, rdur = O.solve_batch_fast(wp, t)
-    assert norm_rel(c_tw, ref) <= 1e-9
-    assert norm_rel(c_os, ref) <= 1e-9
-    assert norm_rel(c_tw, c_os) <= 1e-11
+    ref, rdur = O.solve_batch_fast(wp, t, ncoef=order + 1)
+    tol = 1e-9 if order == 7 else 1e-6       # order 9: the oracle's dense solve is the looser side
+    assert norm_rel(c_tw, ref) <= tol
+    assert norm_rel(c_os, ref) <= tol
+    agree = norm_rel(c_tw, c_os)
+    print(f"order {order} m {m}: two-sided vs one-sided {agree:.2e}, vs oracle {norm_rel(c_tw, ref):.2e} / {norm_rel(c_os, ref):.2e}")
+    assert agree <= (1e-11 if order == 7 else 1e-9), agree
     np.testing.assert_array_equal(d_tw, rdur)
+    np.testing.assert_array_equal(d_os, rdur)
     keep = np.arange(37) != 5                                        # drone 5 has the t[0] quirk: c0 != w_0 there
     np.testing.assert_array_equal(c_tw[keep][..., 0], wp[keep, :-1, :])   # c0 == w_i exactly on both sides
+
+
+def test_failed_drones_in_small_batches_are_nan_filled():
+    """Status codes and NaN fill of the two-sided kernel, for failures on either side of the path
+    and at the meeting knot."""
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    M = 10
+    wp, t = swarm(77, 24, M)
+    t[1, 2] = t[1, 1]                 # side 0: zero-length segment
+    t[2, 9] = t[2, 8] - 0.1           # side 1: decreasing time
+    wp[3, 5, 2] = np.nan              # waypoint at the meeting knot
+    wp[4, 10, 0] = np.inf             # last waypoint
+    t[6, 0] = -1.0                    # negative start time
+    with Context(order=7, max_segments=16) as ctx:
+        coef, dur, status = ctx.solve_batch(wp, t)
+    expect = np.zeros(24, np.int32)
+    expect[[1, 2, 6]] = 2
+    expect[[3, 4]] = 3
+    np.testing.assert_array_equal(status, expect)
+    for d in range(24):
+        if expect[d]:
+            assert np.isnan(coef[d]).all(), d
+        else:
+            assert np.isfinite(coef[d]).all(), d
+    ok = expect == 0
+    import msnap_oracle as O
+    ref, _ = O.solve_batch_fast(wp[ok], t[ok])
+    assert norm_rel(coef[ok], ref) <= 1e-9
 
 
 # ---------------------------------------------------------------------------
