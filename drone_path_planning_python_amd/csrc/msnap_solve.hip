@@ -1236,8 +1236,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
         recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
         if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
         const int seg = side ? M - 1 - it : it;
-        // a batch this small is latency bound, not store bound: plain per-lane stores
-        if (live) {
+        // a batch this small is latency bound, not store bound: plain per-lane stores.  Lanes past
+        // the batch end mirror drone N-1 (same inputs, same values, same addresses), so the stores
+        // need no predicate and the sweep stays one basic block.
+        {
           double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
 #pragma unroll
           for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
