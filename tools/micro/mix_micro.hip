@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
+// the GPU needs ~30 ms of sustained load to reach its steady clocks: warm up well before timing
+constexpr int kWarm = 60, kTimed = 30;
+
 constexpr int kTileBytes = 40960;
 constexpr int kInBytes = 7040;
 
@@ -68,14 +71,14 @@ void run(const double2 *in, double2 *out, int ntiles, int ncu) {
   hipFuncSetAttribute((const void *)tile_mix<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const size_t lds = 20 * 1024;   // 8 single-wave blocks per CU
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((tile_mix<FEAT>), dim3(ncu * 8), dim3(64), lds, 0, in, out, ntiles);
+  for (int i = 0; i < kWarm; ++i) hipLaunchKernelGGL((tile_mix<FEAT>), dim3(ncu * 8), dim3(64), lds, 0, in, out, ntiles);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((tile_mix<FEAT>), dim3(ncu * 8), dim3(64), lds, 0, in, out, ntiles);
+  for (int i = 0; i < kTimed; ++i) hipLaunchKernelGGL((tile_mix<FEAT>), dim3(ncu * 8), dim3(64), lds, 0, in, out, ntiles);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   printf("features %c%c%c%c (in/lds/dpp/fma): %.3f ms\n", (FEAT & 1) ? 'I' : '-', (FEAT & 2) ? 'L' : '-', (FEAT & 4) ? 'D' : '-',
-         (FEAT & 8) ? 'F' : '-', ms / 10);
+         (FEAT & 8) ? 'F' : '-', ms / kTimed);
 }
 
 int main() {

@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
+// the GPU needs ~30 ms of sustained load to reach its steady clocks: warm up well before timing
+constexpr int kWarm = 60, kTimed = 30;
+
 constexpr int kM = 10, kNC = 8;
 constexpr int kOutPerDrone = kM * 4 * kNC;    // doubles
 constexpr int kInPerDrone = (kM + 1) * 4;
@@ -100,25 +103,25 @@ __global__ void __launch_bounds__(64) burst_kernel(const double *in, double *out
 template <int R>
 void run_burst(const double *in, double *out, int nrt, int grid) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((burst_kernel<R>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
+  for (int i = 0; i < kWarm; ++i) hipLaunchKernelGGL((burst_kernel<R>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((burst_kernel<R>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
+  for (int i = 0; i < kTimed; ++i) hipLaunchKernelGGL((burst_kernel<R>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
-  printf("burst R=%2d grid %6d: %.3f ms\n", R, grid, ms / 10);
+  printf("burst R=%2d grid %6d: %.3f ms\n", R, grid, ms / kTimed);
 }
 
 template <int RD>
 void run(const double *in, double *out, int nrt, int grid) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((rw_kernel<RD>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
+  for (int i = 0; i < kWarm; ++i) hipLaunchKernelGGL((rw_kernel<RD>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((rw_kernel<RD>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
+  for (int i = 0; i < kTimed; ++i) hipLaunchKernelGGL((rw_kernel<RD>), dim3(grid), dim3(64), 0, 0, in, out, nrt);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
-  printf("reads %d grid %6d: %.3f ms\n", RD, grid, ms / 10);
+  printf("reads %d grid %6d: %.3f ms\n", RD, grid, ms / kTimed);
 }
 
 int main() {

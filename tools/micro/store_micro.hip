@@ -45,10 +45,10 @@ __global__ void __launch_bounds__(256) fill16(double2 *out, size_t n16) {
 }
 
 template <typename F>
-float time_ms(F launch, int reps = 10) {
+float time_ms(F launch, int reps = 30) {
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  for (int i = 0; i < 2; ++i) launch();
+  for (int i = 0; i < 60; ++i) launch();   // ~30 ms of sustained load: the GPU's clocks have settled
   hipDeviceSynchronize();
   hipEventRecord(a);
   for (int i = 0; i < reps; ++i) launch();
