@@ -65,6 +65,21 @@ __device__ __forceinline__ double dpp_quad_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
+#ifdef MSNAP_EXPERIMENT_TIMELINE
+// phase timestamps (s_memrealtime, 100 MHz) of the GEMM kernel: tools/grid_timeline.py
+__device__ unsigned long long g_grid_timeline[1024 * 8];
+#define MSNAP_GTL(k)                                                                     \
+  do {                                                                                   \
+    if (lane == 0 && blockIdx.x < 1024) g_grid_timeline[blockIdx.x * 8 + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int msnap_debug_read_grid_timeline(unsigned long long *out, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return MSNAP_EHIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_grid_timeline), (size_t)n_words * 8) == hipSuccess ? MSNAP_OK : MSNAP_EHIP;
+}
+#else
+#define MSNAP_GTL(k) do { } while (0)
+#endif
+
 // One instance per (ncoef, segment count): tile counts are constants, so there are no per-tile
 // branches, all column tiles' MFMA chains are issued back to back (independent accumulators keep
 // the matrix pipe full) and only then exchanged and stored.
@@ -79,6 +94,7 @@ grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /
   constexpr int NKS = (m + 3) / 4;
   static_assert(NCT <= kGridMaxCT && NKS <= kGridMaxKS && 4 * M <= kWave, "operator does not fit the registers");
   const int lane = threadIdx.x;
+  MSNAP_GTL(0);
   const int col = lane & 15;
   const int kq = lane >> 4;          // k offset inside a step (A/B operands), axis (D)
   const int grid_st = gstatus[0];
@@ -119,6 +135,7 @@ grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /
       af[ks] = anext[ks];
       nonfin = nonfin || !__builtin_isfinite(af[ks]);
     }
+    MSNAP_GTL(1);
     // the next tile's waypoints are in flight while this tile's MFMAs and stores run
     if (rt + (int)gridDim.x < nrt) load_a(rt + gridDim.x, anext);
     // per-drone non-finite flag: rows 4*dl .. 4*dl+3 of the tile, any k
@@ -162,13 +179,16 @@ grid_gemm_kernel(const double *__restrict__ wp, const double *__restrict__ gop /
         }
       }
     }
+    MSNAP_GTL(2);
     // durations and status of the 4 drones
     if (lane < 4 * M && d0 + r_dur < N) dur[(size_t)d0 * M + lane] = my_dur;
     if (lane < 4 && d0 + lane < N) {
       const unsigned long long dm = 0x000F000F000F000FULL << (4 * lane);
       status[d0 + lane] = (bal & dm) ? MSNAP_ST_NONFINITE : grid_st;
     }
+    MSNAP_GTL(3);
   }
+  MSNAP_GTL(4);
 }
 
 int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device) {
