@@ -3,6 +3,8 @@
 // passes (new capability).  gfx950, wave64.
 #include <math.h>
 
+#include <cstdlib>
+
 #include "msnap_internal.h"
 
 namespace msnap {
@@ -330,6 +332,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // Semantics are this repo's: no reference implementation exists.
 // ------------------------------------------------------------------------------------
 constexpr int kSampleChunk = 6;
+constexpr int kColBlock = 32;     // column drones whose running minima a lane keeps in registers
 
 __global__ void __launch_bounds__(kWave)
 collide_partial_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int row_offset,
@@ -347,72 +350,81 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
   double best = INFINITY;
   int bestj = -1;
   const double *pr = prow + (size_t)r * S * 3;
-  for (int sc = 0; sc < S; sc += kSampleChunk) {
-    // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
-    // seeing a sample twice), so every chunk of a path with S >= 8 takes the wide-load path
-    const int s0 = (S - sc < kSampleChunk && S >= kSampleChunk) ? S - kSampleChunk : sc;
-    const int ns = (S - s0 < kSampleChunk) ? (S - s0) : kSampleChunk;
-    double rx[kSampleChunk], ry[kSampleChunk], rz[kSampleChunk];
+  if (S >= kSampleChunk) {
+    // Columns in blocks of kColBlock: a lane keeps the block's running minima in registers across
+    // all sample chunks, so the inner loop is nothing but the 9 operations per pair and sample
+    // (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the NumPy oracle -- and the
+    // minimum); self-exclusion and the partner bookkeeping happen once per column.
+    for (int jb = c0; jb < c1; jb += kColBlock) {
+      double acc[kColBlock];
 #pragma unroll
-    for (int q = 0; q < kSampleChunk; ++q) {
-      const int sq = (q < ns) ? (s0 + q) : s0;  // tail repeats a valid sample (min unaffected)
-      rx[q] = pr[(size_t)sq * 3 + 0];
-      ry[q] = pr[(size_t)sq * 3 + 1];
-      rz[q] = pr[(size_t)sq * 3 + 2];
-    }
-    if (ns == kSampleChunk) {
-      // full chunk: the column drone's 8 samples are 24 contiguous doubles at a wave-uniform
-      // address -> three wide scalar loads.  Scalar loads only have an all-or-nothing wait, so
-      // the loop is unrolled by two with two register sets: the loads of column j+1 are issued
-      // right after the wait for column j and fly during its 8 x 7 VALU operations.
-      auto fetch = [&](int j, double (&cb)[3 * kSampleChunk]) {
-        const int jc = j < c1 ? j : c1 - 1;
-        const double *pc = pcol + ((size_t)jc * S + s0) * 3;
-#pragma unroll
-        for (int q = 0; q < 3 * kSampleChunk; ++q) cb[q] = pc[q];
-      };
-      auto consume = [&](int j, const double (&cb)[3 * kSampleChunk]) {
-        double m = INFINITY;
+      for (int jj = 0; jj < kColBlock; ++jj) acc[jj] = INFINITY;
+      for (int sc = 0; sc < S; sc += kSampleChunk) {
+        // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
+        // seeing a sample twice), so every chunk takes the wide scalar loads
+        const int s0 = (S - sc < kSampleChunk) ? S - kSampleChunk : sc;
+        double rx[kSampleChunk], ry[kSampleChunk], rz[kSampleChunk];
 #pragma unroll
         for (int q = 0; q < kSampleChunk; ++q) {
-          const double dx = cb[3 * q + 0] - rx[q];
-          const double dy = cb[3 * q + 1] - ry[q];
-          const double dz = cb[3 * q + 2] - rz[q];
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          m = __builtin_fmin(d2, m);
+          rx[q] = pr[(size_t)(s0 + q) * 3 + 0];
+          ry[q] = pr[(size_t)(s0 + q) * 3 + 1];
+          rz[q] = pr[(size_t)(s0 + q) * 3 + 2];
         }
-        if (j == grow || j >= c1) m = INFINITY;
-        if (m < best || (m == best && j < bestj)) {
-          best = m;
-          bestj = j;
+        // the column drone's chunk is 18 contiguous doubles at a wave-uniform address -> wide scalar
+        // loads.  Scalar loads only have an all-or-nothing wait, so two register sets alternate: the
+        // loads of column j+1 are issued right after the wait for column j and fly during its
+        // 6 x 9 VALU operations.
+        auto fetch = [&](int j, double (&cb)[3 * kSampleChunk]) {
+          const int jc = j < c1 ? j : c1 - 1;
+          const double *pc = pcol + ((size_t)jc * S + s0) * 3;
+#pragma unroll
+          for (int q = 0; q < 3 * kSampleChunk; ++q) cb[q] = pc[q];
+        };
+        auto consume = [&](double &m, const double (&cb)[3 * kSampleChunk]) {
+#pragma unroll
+          for (int q = 0; q < kSampleChunk; ++q) {
+            const double dx = cb[3 * q + 0] - rx[q];
+            const double dy = cb[3 * q + 1] - ry[q];
+            const double dz = cb[3 * q + 2] - rz[q];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            m = __builtin_fmin(d2, m);
+          }
+        };
+        double ca[3 * kSampleChunk], cb2[3 * kSampleChunk];
+        fetch(jb, ca);
+#pragma unroll
+        for (int jj = 0; jj < kColBlock; jj += 2) {
+          fetch(jb + jj + 1, cb2);
+          consume(acc[jj], ca);
+          if (jj + 2 < kColBlock) fetch(jb + jj + 2, ca);
+          consume(acc[jj + 1], cb2);
         }
-      };
-      double ca[3 * kSampleChunk], cb2[3 * kSampleChunk];
-      fetch(c0, ca);
-      for (int j = c0; j < c1; j += 2) {
-        fetch(j + 1, cb2);
-        consume(j, ca);
-        fetch(j + 2, ca);
-        consume(j + 1, cb2);
       }
-    } else {
-      for (int j = c0; j < c1; ++j) {
-        const double *pc = pcol + (size_t)j * S * 3;
-        double m = INFINITY;
 #pragma unroll
-        for (int q = 0; q < kSampleChunk; ++q) {
-          const int sq = (q < ns) ? (s0 + q) : s0;
-          const double dx = pc[(size_t)sq * 3 + 0] - rx[q];
-          const double dy = pc[(size_t)sq * 3 + 1] - ry[q];
-          const double dz = pc[(size_t)sq * 3 + 2] - rz[q];
-          const double d2 = dx * dx + dy * dy + dz * dz;
-          m = (d2 < m) ? d2 : m;
-        }
-        if (j == grow) m = INFINITY;
-        if (m < best || (m == best && j < bestj)) {
+      for (int jj = 0; jj < kColBlock; ++jj) {
+        const int j = jb + jj;
+        const double m = (j == grow || j >= c1) ? INFINITY : acc[jj];
+        if (m < best) {     // columns ascend: the lowest index wins a tie
           best = m;
           bestj = j;
         }
+      }
+    }
+  } else {
+    for (int j = c0; j < c1; ++j) {
+      const double *pc = pcol + (size_t)j * S * 3;
+      double m = INFINITY;
+      for (int sq = 0; sq < S; ++sq) {
+        const double dx = pc[(size_t)sq * 3 + 0] - pr[(size_t)sq * 3 + 0];
+        const double dy = pc[(size_t)sq * 3 + 1] - pr[(size_t)sq * 3 + 1];
+        const double dz = pc[(size_t)sq * 3 + 2] - pr[(size_t)sq * 3 + 2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        m = (d2 < m) ? d2 : m;
+      }
+      if (j == grow) m = INFINITY;
+      if (m < best) {
+        best = m;
+        bestj = j;
       }
     }
   }
@@ -422,7 +434,7 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kWave)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, int R, int nsl,
                      double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
                      int32_t *__restrict__ hit) {
@@ -430,12 +442,22 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   if (r >= R) return;
   double best = INFINITY;
   int bj = -1;
-  for (int s = 0; s < nsl; ++s) {
-    const double v = part_d2[(size_t)s * R + r];
-    const int j = part_j[(size_t)s * R + r];
-    if (j >= 0 && (v < best || (v == best && j < bj))) {
-      best = v;
-      bj = j;
+  constexpr int U = 8;      // slices fetched per round: the loads of a round are independent
+  for (int s0 = 0; s0 < nsl; s0 += U) {
+    double v[U];
+    int j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = s0 + u < nsl ? s0 + u : nsl - 1;
+      v[u] = part_d2[(size_t)s * R + r];
+      j[u] = s0 + u < nsl ? part_j[(size_t)s * R + r] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (j[u] >= 0 && (v[u] < best || (v[u] == best && j[u] < bj))) {
+        best = v[u];
+        bj = j[u];
+      }
     }
   }
   const double dist = sqrt(best);
@@ -448,12 +470,20 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                              const double *pos_rows, const double *pos_cols, double radius, double *min_dist,
                              int32_t *partner, int32_t *hit) {
   const int rowblocks = (n_rows + kWave - 1) / kWave;
-  int nsl = (ctx->n_cu * 16 + rowblocks - 1) / rowblocks;
-  const int max_sl = (n_cols + 31) / 32;
-  if (nsl > max_sl) nsl = max_sl;
+  // column slices: enough (row block, slice) waves to fill the chip, each slice a whole number of
+  // kColBlock-column blocks
+  static const int wpc = [] { const char *e = getenv("MSNAP_COLLIDE_WAVES_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+  int nsl = (ctx->n_cu * wpc + rowblocks - 1) / rowblocks;
   if (nsl < 1) nsl = 1;
-  if (nsl > 65535) nsl = 65535;
-  const int cps = (n_cols + nsl - 1) / nsl > 0 ? (n_cols + nsl - 1) / nsl : 1;
+  int cps = (n_cols + nsl - 1) / nsl;
+  cps = (cps + kColBlock - 1) / kColBlock * kColBlock;
+  if (cps < kColBlock) cps = kColBlock;
+  nsl = (n_cols + cps - 1) / cps;
+  if (nsl > 65535) {
+    nsl = 65535;
+    cps = ((n_cols + nsl - 1) / nsl + kColBlock - 1) / kColBlock * kColBlock;
+    nsl = (n_cols + cps - 1) / cps;
+  }
   const size_t wbytes = (size_t)nsl * n_rows * (sizeof(double) + sizeof(int32_t));
   int rc = ensure(ctx, ctx->stage[7], wbytes);
   if (rc) return rc;
@@ -462,7 +492,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   hipLaunchKernelGGL(collide_partial_kernel, dim3(rowblocks, nsl), dim3(kWave), 0, ctx->stream, pos_rows,
                      pos_cols, n_rows, row_offset, n_cols, n_samples, cps, pd, pj);
   MSNAP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, pd, pj,
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ctx->stream, pd, pj,
                      n_rows, nsl, radius, min_dist, partner, hit);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
