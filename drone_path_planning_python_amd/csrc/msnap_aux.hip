@@ -567,10 +567,14 @@ mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__
   const int d = blockIdx.x;
   const int lane = threadIdx.x;
   double best = INFINITY;
-  for (int s = lane; s < S; s += kWave) {
+  // Typical paths have 64 < S < 128 samples: with one sample per lane the second pass would run
+  // half empty.  The wave is split instead: 32 samples per pass, the two half-waves take the even
+  // and the odd triangles (the triangle is then uniform per half-wave, its 9 doubles come from L1).
+  const int sl = lane & 31, half = lane >> 5;
+  for (int s = sl; s < S; s += 32) {
     const double *p = pos + ((size_t)d * S + s) * 3;
     const double px = p[0], py = p[1], pz = p[2];
-    for (int t = 0; t < n_tris; ++t) {
+    for (int t = half; t < n_tris; t += 2) {
       const double v = pt_tri_d2(px, py, pz, tris + (size_t)t * 9);
       best = (v < best) ? v : best;
     }
