@@ -502,3 +502,32 @@ def test_pinned_arrays_outlive_their_views():
     gc.collect()
     assert (row == 1.5).all()
     assert pinned_empty((0, 4)).shape == (0, 4)
+
+
+# ---------------------------------------------------------------------------
+# seeded sweep over shapes: every kernel-selection branch against the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_against_oracle(ctx7, ctx9, seed):
+    """Random batch size, segment count, order, shared / per-drone grid, start-time quirk: whatever
+    kernel variant the launcher picks must reproduce the oracle's dense solve."""
+    import msnap_oracle as O
+    rng = np.random.default_rng(9000 + seed)
+    order = 7 if seed % 3 else 9
+    ctx = ctx7 if order == 7 else ctx9
+    M = int(rng.integers(1, 27 if order == 7 else 15))
+    N = int(rng.choice([1, 2, 7, 8, 9, 16, 31, 64, 65, 130]))
+    shared = bool(rng.integers(0, 2))
+    wp = rng.uniform(-5, 5, size=(N, M + 1, 4))
+    wp[..., 3] = rng.uniform(-np.pi, np.pi, size=(N, M + 1))
+    T = rng.uniform(0.4, 2.5, size=(1 if shared else N, M))
+    t = np.concatenate([np.zeros((T.shape[0], 1)), np.cumsum(T, axis=1)], axis=1)
+    if not shared and N > 2:
+        t[1] += 0.25                       # the reference's start-row quirk on one drone
+    tt = t[0] if shared else t
+    coef, dur, status = ctx.solve_batch(wp, tt)
+    assert (status == 0).all()
+    ref, rdur = O.solve_batch_fast(wp, np.broadcast_to(t, (N, M + 1)) if shared else t, ncoef=order + 1)
+    err = norm_rel(coef, ref)
+    assert err <= (TIGHT if order == 7 else TOL), (order, N, M, shared, err)
+    np.testing.assert_array_equal(dur, rdur)
