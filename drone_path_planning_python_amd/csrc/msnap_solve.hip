@@ -44,18 +44,14 @@ __device__ __forceinline__ constexpr int sidx(int r, int c) {  // symmetric lowe
 }
 
 __device__ __forceinline__ double rcp64(double v) {
-#ifdef MSNAP_EXACT_DIV
-  return 1.0 / v;
-#else
-  // v_rcp_f64 seed + two Newton steps; inputs are durations / SPD pivots in a
-  // sane range (status flags catch the rest), so no denormal/overflow fix-up.
+  // v_rcp_f64 seed (2^-24) + two Newton steps (1 ulp, tools/micro/rcp_micro.hip); inputs are
+  // durations / SPD pivots in a sane range (status flags catch the rest), so no denormal/overflow fix-up.
   double r = __builtin_amdgcn_rcp(v);
   double e = __builtin_fma(-v, r, 1.0);
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-v, r, 1.0);
   r = __builtin_fma(r, e, r);
   return r;
-#endif
 }
 
 __device__ __forceinline__ bool finite64(double v) { return __builtin_isfinite(v); }
@@ -305,13 +301,8 @@ __device__ __forceinline__ void store_segment(double *__restrict__ o, double (&c
 // LDS is in-order within a wave; the wavefront-scope fences only pin the
 // compiler's ordering (no vmcnt wait: output stores stay in flight).
 constexpr int kTrPitch = 68;
-#ifdef MSNAP_EXPERIMENT_LINEAR_TILE   // timing experiment only (WRONG layout): a tile-segment is contiguous
-#define MSNAP_SEG_BASE(coef, tile, M, i, NC) ((coef) + ((size_t)(tile) * kDronesPerWave * (M) + (size_t)(i) * kDronesPerWave) * (4 * (NC)))
-#define MSNAP_SEG_STRIDE(M, NC) ((size_t)4 * (NC))
-#else
 #define MSNAP_SEG_BASE(coef, tile, M, i, NC) ((coef) + ((size_t)(tile) * kDronesPerWave * (M) + (i)) * (4 * (NC)))
 #define MSNAP_SEG_STRIDE(M, NC) ((size_t)(M) * 4 * (NC))
-#endif
 template <int NC>
 __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__restrict__ seg_base,
                                                         size_t drone_stride, int nvalid, int lane,
@@ -942,11 +933,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], xreg[i], u, un, c);
 #endif
         if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-#ifdef MSNAP_EXPERIMENT_LDS_TR
-        if constexpr (false)
-#else
         if constexpr (NC == 8)
-#endif
           store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
         else
           store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
