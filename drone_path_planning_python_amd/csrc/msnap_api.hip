@@ -119,6 +119,7 @@ void msnap_destroy(msnap_ctx *ctx) {
     if (ctx->pipe_stream[k]) (void)hipStreamDestroy(ctx->pipe_stream[k]);
   }
   if (ctx->pipe_start) (void)hipEventDestroy(ctx->pipe_start);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -185,6 +186,8 @@ int msnap_timer_stop(msnap_ctx *ctx, float *elapsed_ms) {
 // (msnap_host_alloc) both copy engines then run at PCIe rate, with pageable memory the HIP
 // runtime serialises the copies and the result is the same as one big copy.  Device staging is
 // bounded by two chunks, whatever the batch size.
+constexpr size_t kBounceMax = 1u << 20;   // bytes of inputs + outputs that take the single-bounce path
+
 static int solve_host(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, const double *t, int shared,
                       bool use_grid, double *coef, double *dur, int32_t *status) {
   const size_t m = (size_t)n_seg + 1, nc = ctx->order + 1;
@@ -199,6 +202,40 @@ static int solve_host(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp,
     return use_grid ? launch_solve_grid(ctx, (int)n, dwp, dcoef, ddur, dst)
                     : launch_solve(ctx, (int)n, n_seg, dwp, dt, shared, dcoef, ddur, dst);
   };
+  // Small batches (the reference's own call is ONE trajectory): everything goes through one
+  // page-locked bounce buffer laid out like the device staging block [wp | t | coef | dur | status],
+  // so a call is one upload, the kernel, one download and one synchronise instead of five pageable
+  // copies (60 -> ~30 us per call).
+  auto up256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t b_t = t ? (shared ? 1 : N) * pd_t : 0;
+  const size_t o_t = up256(N * pd_wp), in_bytes = up256(o_t + b_t);                  // [wp | t]
+  const size_t o_coef = in_bytes, o_dur = o_coef + up256(N * pd_coef), o_st = o_dur + up256(N * pd_dur);
+  const size_t out_bytes = o_st + up256(N * pd_st) - o_coef;                          // [coef | dur | status]
+  if (in_bytes + out_bytes <= kBounceMax && !solve_uses_global_scratch(ctx, n_seg)) {
+    if (!ctx->bounce) {
+      if (hipHostMalloc(&ctx->bounce, kBounceMax, hipHostMallocDefault) != hipSuccess) {
+        ctx->bounce = nullptr;
+        (void)hipGetLastError();
+      } else {
+        ctx->bounce_cap = kBounceMax;
+      }
+    }
+    if (ctx->bounce && (rc = ensure(ctx, ctx->stage[5], kBounceMax)) == MSNAP_OK) {
+      char *hb = (char *)ctx->bounce, *db = (char *)ctx->stage[5].p;
+      memcpy(hb, wp, N * pd_wp);
+      if (t) memcpy(hb + o_t, t, b_t);
+      MSNAP_HIP(ctx, hipMemcpyAsync(db, hb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+      rc = launch(N, (const double *)db, (const double *)(db + o_t), (double *)(db + o_coef), (double *)(db + o_dur),
+                  (int32_t *)(db + o_st));
+      if (rc) return rc;
+      MSNAP_HIP(ctx, hipMemcpyAsync(hb + o_coef, db + o_coef, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      memcpy(coef, hb + o_coef, N * pd_coef);
+      memcpy(dur, hb + o_dur, N * pd_dur);
+      memcpy(status, hb + o_st, N * pd_st);
+      return MSNAP_OK;
+    }
+  }
   if (N <= chunk || solve_uses_global_scratch(ctx, n_seg)) {
     // one shot on the context's stream
     if ((rc = ensure(ctx, ctx->stage[0], N * pd_wp))) return rc;

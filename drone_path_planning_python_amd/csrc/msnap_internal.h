@@ -77,6 +77,9 @@ struct msnap_ctx {
   hipEvent_t pipe_start = nullptr;
   msnap::DevBuf pipe[2][5];
   size_t pipe_chunk_bytes = 64u << 20;   // output bytes per chunk (MSNAP_PIPE_CHUNK_MB overrides)
+  // small host-pointer solves: one page-locked bounce buffer, one upload and one download per call
+  void *bounce = nullptr;
+  size_t bounce_cap = 0;
   // shared-time-grid operator (K2): built by msnap_grid_prepare
   msnap::DevBuf grid_t, grid_wp, grid_op, grid_dur, grid_status, grid_frag;
   int grid_seg = 0;
