@@ -21,6 +21,8 @@
 // instruction (fixed reg) covers [2 segments][4 axes][8 coefs] = 512 contiguous
 // bytes of one drone at order 7.  Every wave keeps the whole Gop in registers
 // (B fragments) and streams row tiles: the kernel is bound by the output stores.
+#include <cstdlib>
+
 #include "msnap_internal.h"
 
 namespace msnap {
@@ -238,6 +240,7 @@ int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *co
   const int nc = ctx->order + 1;
   const int nrt = (n_drones + 3) / 4;
   int grid = ctx->n_cu * 8;
+  if (const char *e = getenv("MSNAP_EXPERIMENT_GEMM_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
   if (grid > nrt) grid = nrt;
 #define MSNAP_GRID_CASE(NCV, MM)                                                                       \
   case MM:                                                                                             \

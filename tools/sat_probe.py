@@ -2,11 +2,12 @@ import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from drone_path_planning_python_amd import Context
 from drone_path_planning_python_amd.synthetic import swarm
-ctx = Context(0, 7, 64); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-N = 1 << 20; M = 10
-wp, t = swarm(2, 4096, M); wp = np.tile(wp, (256, 1, 1)); t = np.tile(t, (256, 1))
+import os
+ORDER = int(os.environ.get("PROBE_ORDER", "7")); M = int(os.environ.get("PROBE_M", "10")); N = int(os.environ.get("PROBE_N", str(1 << 20)))
+ctx = Context(0, ORDER, 64); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+wp, t = swarm(2, 4096, M); wp = np.tile(wp, (N // 4096, 1, 1)); t = np.tile(t, (N // 4096, 1))
 tw = torch.from_numpy(wp).cuda(); tt = torch.from_numpy(t).cuda()
-coef = torch.empty((N, M, 4, 8), dtype=torch.float64, device="cuda")
+coef = torch.empty((N, M, 4, ORDER + 1), dtype=torch.float64, device="cuda")
 dur = torch.empty((N, M), dtype=torch.float64, device="cuda"); st = torch.empty((N,), dtype=torch.int32, device="cuda")
 for _ in range(40): ctx.solve_batch_device(N, M, tw, tt, False, coef, dur, st)
 torch.cuda.synchronize()
