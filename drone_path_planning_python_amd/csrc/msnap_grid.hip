@@ -239,7 +239,9 @@ int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *co
   }
   const int nc = ctx->order + 1;
   const int nrt = (n_drones + 3) / 4;
-  int grid = ctx->n_cu * 8;
+  // 8x the resident set: the hardware starts waves as others retire, which staggers their phases
+  // (0.655 -> 0.641 ms at 2^20 drones; one wave per tile loses the operator's register residency: 0.76 ms)
+  int grid = ctx->n_cu * 64;
   if (const char *e = getenv("MSNAP_EXPERIMENT_GEMM_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
   if (grid > nrt) grid = nrt;
 #define MSNAP_GRID_CASE(NCV, MM)                                                                       \
