@@ -22,11 +22,12 @@
 // (S_i, G_i) depends on the time grid only and is recomputed by the 4 axis
 // lanes of a drone (no cross-lane traffic, no divergence: every lane runs the
 // same M-step recurrence).  The tile's inputs are staged in LDS by one
-// coalesced sweep.  The variants share the arithmetic (Sweep<K>::step, recover_segment)
+// coalesced sweep.  The variants share the arithmetic (Sweep<K>::knot_geom / chain, recover_segment)
 // and are chosen per launch by launch_solve_k:
-//   solve_kernel_twist<H,M>    order 7, 3 <= n_seg <= 24, batch below one wavefront per CU:
-//                              two-sided sweep (halves the dependent chain), one straight-line
-//                              instance per n_seg                            (latency path)
+//   solve_kernel_twist<K,H,M>  2 <= n_seg <= 24 (order 7) / 12 (order 9), batch up to one 8-drone
+//                              wavefront per SIMD: two-sided sweep (halves the dependent chain)
+//                              meeting at a shared knot, one straight-line instance per
+//                              (order, n_seg)                                (latency path)
 //   solve_kernel_reg<K,10|20>  n_seg <= 20: knot loops unrolled, path data and z_i in
 //                              registers, G_i in LDS, persistent waves with cross-tile
 //                              input prefetch                               (throughput path)
