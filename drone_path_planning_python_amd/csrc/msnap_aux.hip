@@ -50,9 +50,19 @@ __global__ void __launch_bounds__(256)
 formation_kernel(const double *__restrict__ rb, const double *__restrict__ off, double *__restrict__ out,
                  int P, int Kn) {
 #pragma clang fp contract(off)
+  // A wave's 64 (offset, pose) items own 448 CONSECUTIVE output doubles; written per lane they would be
+  // seven 8-B stores at a 56-B stride.  Through a per-wave LDS image (stride 7 is odd: conflict-free both
+  // ways) they leave as seven stores of 512 contiguous bytes.
+  __shared__ double image[4][kWave * 7];
+  const int lane = threadIdx.x & (kWave - 1);
+  double *img = image[threadIdx.x / kWave];
   const size_t total = (size_t)P * Kn;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
+  const size_t span = (size_t)gridDim.x * blockDim.x;
+  const size_t trips = (total + span - 1) / span;      // the same for every wave: no partly exited wave below
+  for (size_t trip = 0; trip < trips; ++trip) {
+    const size_t wave_base = trip * span + (size_t)blockIdx.x * blockDim.x + (threadIdx.x - lane);
+    const size_t idx = wave_base + lane;
+    if (idx < total) {
     const int k = (int)(idx / P);
     const int p = (int)(idx - (size_t)k * P);
     const double *r = rb + (size_t)p * 7;
@@ -63,7 +73,7 @@ formation_kernel(const double *__restrict__ rb, const double *__restrict__ off, 
     const double m10 = 2 * x * y + 2 * w * z, m11 = w2 - x2 + y2 - z2, m12 = 2 * y * z - 2 * w * x;
     const double m20 = 2 * x * z - 2 * w * y, m21 = 2 * y * z + 2 * w * x, m22 = w2 - x2 - y2 + z2;
     const double ox = off[k * 3 + 0], oy = off[k * 3 + 1], oz = off[k * 3 + 2];
-    double *o = out + idx * 7;
+    double *o = img + lane * 7;
     o[0] = m00 * ox + m01 * oy + m02 * oz + tx;
     o[1] = m10 * ox + m11 * oy + m12 * oz + ty;
     o[2] = m20 * ox + m21 * oy + m22 * oz + tz;
@@ -99,6 +109,18 @@ formation_kernel(const double *__restrict__ rb, const double *__restrict__ off, 
     o[4] = qy;
     o[5] = qz;
     o[6] = qw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    const size_t ebase = wave_base * 7, nelem = total * 7;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int e = j * kWave + lane;
+      if (ebase + e < nelem) out[ebase + e] = img[e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
