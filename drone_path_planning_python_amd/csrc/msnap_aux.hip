@@ -350,7 +350,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // Formation pass: for every owned drone i the minimum over all other drones j and
 // all common samples s of |p_i(s) - p_j(s)|.  One lane per row drone; the column
 // drone is wave-uniform, so its samples come through the scalar cache.  The
-// column range is sliced over blockIdx.y; a second tiny kernel merges slices.
+// column range is sliced over blockIdx.x; a second tiny kernel merges slices.
 // Semantics are this repo's: no reference implementation exists.
 // ------------------------------------------------------------------------------------
 constexpr int kSampleChunk = 6;
@@ -362,11 +362,14 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
                        int32_t *__restrict__ part_j) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x;
-  const int r_raw = blockIdx.x * kWave + lane;
+  // Workgroup ids advance along the column slices first: consecutive ids land on different XCDs, so an
+  // XCD keeps meeting the same few slices and their column data stays in its L2 / scalar caches.
+  const int rb = blockIdx.y, sl = blockIdx.x;
+  const int r_raw = rb * kWave + lane;
   const bool live = r_raw < R;
   const int r = live ? r_raw : R - 1;
   const int grow = row_offset + r;
-  const int c0 = blockIdx.y * cols_per_slice;
+  const int c0 = sl * cols_per_slice;
   int c1 = c0 + cols_per_slice;
   if (c1 > Cn) c1 = Cn;
   double best = INFINITY;
@@ -451,8 +454,8 @@ collide_partial_kernel(const double *__restrict__ prow, const double *__restrict
     }
   }
   if (live) {
-    part_d2[(size_t)blockIdx.y * R + r] = best;
-    part_j[(size_t)blockIdx.y * R + r] = (best == INFINITY) ? -1 : bestj;
+    part_d2[(size_t)sl * R + r] = best;
+    part_j[(size_t)sl * R + r] = (best == INFINITY) ? -1 : bestj;
   }
 }
 
@@ -494,7 +497,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   const int rowblocks = (n_rows + kWave - 1) / kWave;
   // column slices: enough (row block, slice) waves to fill the chip, each slice a whole number of
   // kColBlock-column blocks
-  static const int wpc = [] { const char *e = getenv("MSNAP_COLLIDE_WAVES_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+  static const int wpc = [] { const char *e = getenv("MSNAP_COLLIDE_WAVES_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
   int nsl = (ctx->n_cu * wpc + rowblocks - 1) / rowblocks;
   if (nsl < 1) nsl = 1;
   int cps = (n_cols + nsl - 1) / nsl;
@@ -511,7 +514,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   if (rc) return rc;
   double *pd = (double *)ctx->stage[7].p;
   int32_t *pj = (int32_t *)(pd + (size_t)nsl * n_rows);
-  hipLaunchKernelGGL(collide_partial_kernel, dim3(rowblocks, nsl), dim3(kWave), 0, ctx->stream, pos_rows,
+  hipLaunchKernelGGL(collide_partial_kernel, dim3(nsl, rowblocks), dim3(kWave), 0, ctx->stream, pos_rows,
                      pos_cols, n_rows, row_offset, n_cols, n_samples, cps, pd, pj);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ctx->stream, pd, pj,
