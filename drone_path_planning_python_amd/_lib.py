@@ -30,6 +30,8 @@ SIGNATURES = {
     "msnap_destroy": (None, [_VP]),
     "msnap_set_stream": (_I, [_VP, _VP]),
     "msnap_use_own_stream": (_I, [_VP]),
+    "msnap_set_option": (_I, [_VP, ctypes.c_char_p, ctypes.c_long]),
+    "msnap_get_option": (_I, [_VP, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]),
     "msnap_host_alloc": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]),
     "msnap_host_free": (_I, [_VP]),
     "msnap_get_stream": (_VP, [_VP]),

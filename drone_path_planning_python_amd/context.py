@@ -116,6 +116,31 @@ class Context:
     def _ck(self, rc):
         _lib.check(self._lib, self._h, rc)
 
+    # ---- launch-geometry options (msnap_set_option) ------------------------------
+    def set_option(self, name: str, value: int):
+        """Launch-geometry knob of this context (include/msnap.h lists the names), e.g.
+        set_option("solve_grid_waves", 5) makes every wave of the large-batch solve walk
+        several tiles on a batch small enough for the oracle."""
+        with self._lock:
+            self._ck(self._lib.msnap_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_long()
+        self._ck(self._lib.msnap_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def _coef_dur(self, coef, dur):
+        """Validated host (coef [N,M,4,ncoef], dur [N,M]) and their pointers."""
+        coef, pc = _host(coef, np.float64)
+        dur, pd = _host(dur, np.float64)
+        if dur.ndim != 2:
+            raise ValueError("dur must be [N, M]")
+        N, M = dur.shape
+        if coef.shape != (N, M, 4, self.ncoef):
+            raise ValueError(f"coef must be [N, M, 4, {self.ncoef}] = {(N, M, 4, self.ncoef)} for this "
+                             f"order-{self.order} context, got {coef.shape}")
+        return coef, pc, dur, pd, N, M
+
     # ---- stream / timing ------------------------------------------------------
     def set_stream(self, hip_stream: int | None):
         """Launch on an external hipStream_t (0 / None = the HIP null stream)."""
@@ -215,9 +240,7 @@ class Context:
 
     # ---- a7 pack ---------------------------------------------------------------
     def pack_pol_matrix(self, coef, dur):
-        coef, pc = _host(coef, np.float64)
-        dur, pd = _host(dur, np.float64)
-        N, M = dur.shape
+        coef, pc, dur, pd, N, M = self._coef_dur(coef, dur)
         out = np.empty((N, M, 1 + 4 * self.ncoef), dtype=np.float32)
         with self._lock:
             self._ck(self._lib.msnap_pack_pol_matrix(self._h, N, M, pc, pd, out.ctypes.data_as(ctypes.c_void_p)))
@@ -248,9 +271,7 @@ class Context:
 
     # ---- a5 sampler ------------------------------------------------------------
     def sample(self, coef, dur, dt: float, n_samples: int, n_axes: int = 3):
-        coef, pc = _host(coef, np.float64)
-        dur, pd = _host(dur, np.float64)
-        N, M = dur.shape
+        coef, pc, dur, pd, N, M = self._coef_dur(coef, dur)
         pos = np.empty((N, int(n_samples), int(n_axes)), dtype=np.float64)
         with self._lock:
             self._ck(self._lib.msnap_sample(self._h, N, M, pc, pd, float(dt), int(n_samples), int(n_axes),
@@ -265,10 +286,10 @@ class Context:
     # ---- flatness evaluator (Trajectory.eval) -------------------------------------
     def eval_flat(self, coef, dur, ts):
         """coef [N,M,4,nc], dur [N,M], ts [S] -> out [N,S,13] = pos3 vel3 acc3 omega3 yaw."""
-        coef, pc = _host(coef, np.float64)
-        dur, pd = _host(dur, np.float64)
+        coef, pc, dur, pd, N, M = self._coef_dur(coef, dur)
         ts, pt = _host(ts, np.float64)
-        N, M = dur.shape
+        if ts.ndim != 1:
+            raise ValueError("ts must be [S]")
         S = ts.shape[0]
         out = np.empty((N, S, 13), dtype=np.float64)
         with self._lock:
@@ -283,9 +304,7 @@ class Context:
     # ---- snap cost ---------------------------------------------------------------------
     def snap_cost(self, coef, dur):
         """J = sum_seg int (p^(k))^2 dt per drone and axis -> [N, 4]."""
-        coef, pc = _host(coef, np.float64)
-        dur, pd = _host(dur, np.float64)
-        N, M = dur.shape
+        coef, pc, dur, pd, N, M = self._coef_dur(coef, dur)
         cost = np.empty((N, 4), dtype=np.float64)
         with self._lock:
             self._ck(self._lib.msnap_snap_cost(self._h, N, M, pc, pd, cost.ctypes.data_as(ctypes.c_void_p)))
@@ -300,10 +319,10 @@ class Context:
     def formation_collide(self, pos_rows, pos_cols, radius: float, row_offset: int = 0):
         pr, ppr = _host(pos_rows, np.float64)
         pc, ppc = _host(pos_cols, np.float64)
+        if pr.ndim != 3 or pr.shape[2] != 3 or pc.ndim != 3 or pc.shape[1:] != pr.shape[1:]:
+            raise ValueError("pos_rows [R,S,3] and pos_cols [C,S,3] must share S")
         R, S, _ = pr.shape
         Cn = pc.shape[0]
-        if pc.shape[1:] != (S, 3) or pr.shape[2] != 3:
-            raise ValueError("pos_rows [R,S,3] and pos_cols [C,S,3] must share S")
         md = np.empty((R,), dtype=np.float64)
         partner = np.empty((R,), dtype=np.int32)
         hit = np.empty((R,), dtype=np.int32)
@@ -324,6 +343,10 @@ class Context:
     def mesh_sweep(self, pos, tris, radius: float):
         p, pp = _host(pos, np.float64)
         tr, ptr_ = _host(tris, np.float64)
+        if p.ndim != 3 or p.shape[2] != 3:
+            raise ValueError("pos must be [N, S, 3]")
+        if tr.ndim != 3 or tr.shape[1:] != (3, 3):
+            raise ValueError("tris must be [T, 3, 3]")
         N, S, _ = p.shape
         Tn = tr.shape[0]
         md = np.empty((N,), dtype=np.float64)
@@ -342,6 +365,8 @@ class Context:
         et, pet = _host(env_tris, np.float64)
         if st.ndim != 2 or st.shape[1] != 4:
             raise ValueError("states must be [N, 4]")
+        if rt.ndim != 3 or rt.shape[1:] != (3, 3) or et.ndim != 3 or et.shape[1:] != (3, 3):
+            raise ValueError("robot_tris / env_tris must be [T, 3, 3]")
         N = st.shape[0]
         valid = np.empty((N,), dtype=np.int32)
         with self._lock:

@@ -39,6 +39,24 @@ static int check_seg(const msnap_ctx *ctx, int n_seg) {
   return MSNAP_OK;
 }
 
+struct OptionName {
+  const char *name, *env;
+};
+static const OptionName kOptions[] = {
+    {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
+    {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
+    {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
+};
+
+static int *option_slot(msnap_ctx *ctx, const char *name) {
+  if (!strcmp(name, "solve_grid_waves")) return &ctx->solve_grid_waves;
+  if (!strcmp(name, "gemm_grid_waves")) return &ctx->gemm_grid_waves;
+  if (!strcmp(name, "twist_max_drones")) return &ctx->twist_max_drones;
+  if (!strcmp(name, "no_twist")) return &ctx->no_twist;
+  if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
+  return nullptr;
+}
+
 }  // namespace msnap
 
 using namespace msnap;
@@ -77,13 +95,10 @@ int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
   ctx->order = order;
   ctx->khalf = (order + 1) / 2;
   ctx->max_segments = max_segments;
-  {
-    const char *e = getenv("MSNAP_NO_TWIST");
-    ctx->no_twist = (e && e[0] == '1') ? 1 : 0;
-    e = getenv("MSNAP_TWIST_MAX_DRONES");
-    if (e && atol(e) > 0) ctx->twist_max_drones = (int)atol(e);
-    e = getenv("MSNAP_PIPE_CHUNK_MB");
-    if (e && atol(e) > 0) ctx->pipe_chunk_bytes = (size_t)atol(e) << 20;
+  // the only place the environment is read: seeds of the msnap_set_option knobs
+  for (const OptionName &o : kOptions) {
+    const char *e = getenv(o.env);
+    if (e && atol(e) > 0) (void)msnap_set_option(ctx, o.name, atol(e));
   }
   int rc = MSNAP_OK;
   do {
@@ -135,6 +150,30 @@ int msnap_set_stream(msnap_ctx *ctx, void *hip_stream) {
 int msnap_use_own_stream(msnap_ctx *ctx) {
   if (!ctx) return MSNAP_EINVAL;
   ctx->stream = ctx->own_stream;
+  return MSNAP_OK;
+}
+
+int msnap_set_option(msnap_ctx *ctx, const char *name, long value) {
+  if (!ctx || !name || value < 0 || value > (1L << 30)) return MSNAP_EINVAL;
+  if (!strcmp(name, "pipe_chunk_mb")) {
+    ctx->pipe_chunk_bytes = (size_t)(value > 0 ? value : 64) << 20;
+    return MSNAP_OK;
+  }
+  int *slot = option_slot(ctx, name);
+  if (!slot) return MSNAP_EINVAL;
+  *slot = (int)value;
+  return MSNAP_OK;
+}
+
+int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
+  if (!ctx || !name || !value) return MSNAP_EINVAL;
+  if (!strcmp(name, "pipe_chunk_mb")) {
+    *value = (long)(ctx->pipe_chunk_bytes >> 20);
+    return MSNAP_OK;
+  }
+  const int *slot = option_slot(const_cast<msnap_ctx *>(ctx), name);
+  if (!slot) return MSNAP_EINVAL;
+  *value = *slot;
   return MSNAP_OK;
 }
 

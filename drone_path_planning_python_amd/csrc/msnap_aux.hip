@@ -495,9 +495,17 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                              const double *pos_rows, const double *pos_cols, double radius, double *min_dist,
                              int32_t *partner, int32_t *hit) {
   const int rowblocks = (n_rows + kWave - 1) / kWave;
+  if (rowblocks > 65535) return MSNAP_EINVAL;   // grid y dimension: n_rows <= 65535 * 64 per call (msnap.h)
+  if (n_cols == 0) {
+    // nobody to collide with: the merge of zero slices writes inf / -1 / 0
+    hipLaunchKernelGGL(collide_merge_kernel, dim3(rowblocks), dim3(64), 0, ctx->stream, (const double *)nullptr,
+                       (const int32_t *)nullptr, n_rows, 0, radius, min_dist, partner, hit);
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
+  }
   // column slices: enough (row block, slice) waves to fill the chip, each slice a whole number of
   // kColBlock-column blocks
-  static const int wpc = [] { const char *e = getenv("MSNAP_COLLIDE_WAVES_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
+  const int wpc = ctx->collide_waves_per_cu > 0 ? ctx->collide_waves_per_cu : 32;
   int nsl = (ctx->n_cu * wpc + rowblocks - 1) / rowblocks;
   if (nsl < 1) nsl = 1;
   int cps = (n_cols + nsl - 1) / nsl;

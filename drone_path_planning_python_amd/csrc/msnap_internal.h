@@ -84,8 +84,13 @@ struct msnap_ctx {
   msnap::DevBuf grid_t, grid_wp, grid_op, grid_dur, grid_status, grid_frag;
   int grid_seg = 0;
   int grid_ready = 0;
-  int no_twist = 0;        // MSNAP_NO_TWIST=1: keep small batches on the one-sided kernels (A/B timing)
-  int twist_max_drones = 0; // batches up to this size take the two-sided small-batch kernel (0: default)
+  // launch-geometry options (msnap_set_option; the MSNAP_* environment variables of msnap.h only
+  // seed them in msnap_create -- nothing on a launch path reads the environment)
+  int no_twist = 0;             // "no_twist": keep small batches on the one-sided kernels (A/B timing)
+  int twist_max_drones = 0;     // "twist_max_drones": batches up to this size take the small-batch kernel (0: default)
+  int solve_grid_waves = 0;     // "solve_grid_waves": cap on solve_kernel_reg's persistent grid (0: default)
+  int gemm_grid_waves = 0;      // "gemm_grid_waves": cap on the shared-grid GEMM's persistent grid (0: default)
+  int collide_waves_per_cu = 0; // "collide_waves_per_cu": (row block, slice) waves per CU of the pairwise pass (0: 32)
   char hip_err[256] = {0};
 };
 

@@ -284,9 +284,6 @@ __device__ __forceinline__ void store_segment(double *__restrict__ o, double (&c
 #pragma unroll
     for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
   }
-#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
-  live = live && (c[0] == 12345.678);
-#endif
   if (live) {
 #pragma unroll
     for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
@@ -327,9 +324,6 @@ __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__
     const int j2 = within - a2 * NJ;
     const double2 v = sTr[j2 * kTrPitch + drone * 4 + a2];
     bool ok = drone < nvalid;
-#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
-    ok = ok && (v.x == 12345.678);
-#endif
     if (ok) *reinterpret_cast<double2 *>(seg_base + (size_t)drone * drone_stride + within * 2) = v;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -378,9 +372,6 @@ __device__ __forceinline__ void store_quad8_at(double *__restrict__ blk, bool ok
   quad_exchange<0x4E>(p1x, p3x, b1);
   quad_exchange<0x4E>(p1y, p3y, b1);
   // now piece q = coefficient pair `a` of axis q
-#ifdef MSNAP_EXPERIMENT_NO_STORE   // timing experiment only: keeps the arithmetic alive
-  ok = ok && (p0x == 12345.678);
-#endif
   if (ok) {
     double *o = blk + a * 2;
     *reinterpret_cast<double2 *>(o + 0) = make_double2(p0x, p0y);
@@ -795,21 +786,13 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   StageRegsAsm<MAXM> pre;
   if ((int)blockIdx.x < ntiles)
     stage_load_asm(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane, pre);
-  // Prefetch distance.  Under a write-saturated memory system a read takes several microseconds, so
-  // the next tile's inputs are requested as early as their registers allow: right after the forward
-  // sweep (whose state is dead by then) when all of the tile's output-store instructions fit the
-  // 6-bit vmcnt field (kEarly), otherwise two segments before the end.  `stores_after_prefetch`
-  // is the exact number of younger store instructions the wait must leave in flight.
+  // Prefetch distance: the next tile's inputs are requested two segments before the end of the
+  // backward sweep, when most of this tile's registers are dead.  (Requesting them right after the
+  // forward sweep hides more latency on paper but measured 4 % slower at saturation)
+  // `stores_after_prefetch` is the exact number of younger store instructions the wait must leave
+  // in flight; tools/check_prefetch_isa.py checks it against the code object at build time.
   constexpr int kStoresPerSeg = (NC == 8 ? 4 : NC / 2);
-  // Issuing the next tile's loads before the backward sweep (MSNAP_EXPERIMENT_EARLY_PREFETCH) hides
-  // more latency on paper but measured 4% slower at saturation (0.81 vs 0.78 ms): the loads then
-  // queue behind fewer stores and the wave holds the staging registers through the whole sweep.
-#ifdef MSNAP_EXPERIMENT_EARLY_PREFETCH
-  constexpr bool kEarly = kStoresPerSeg * MAXM <= 60;
-#else
-  constexpr bool kEarly = false;
-#endif
-  const int stores_after_prefetch = kStoresPerSeg * (kEarly ? M : (M >= 2 ? 2 : 1));
+  const int stores_after_prefetch = kStoresPerSeg * (M >= 2 ? 2 : 1);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d_raw = tile * kDronesPerWave + dl;
@@ -860,12 +843,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         badtime |= !(Ti > 0.0);
         xreg[i] = rcp64(Ti);
         double G[NU][NU], z[NU];
-#ifdef MSNAP_EXPERIMENT_STORE_ONLY
-#pragma unroll
-        for (int r = 0; r < NU; ++r) { z[r] = xreg[i]; for (int c = 0; c < NU; ++c) G[r][c] = wreg[i]; }
-#else
         sw.step(xreg[i], wreg[i + 1] - wreg[i], G, z);
-#endif
         if (i < M - 1) {
           double *g = sG + (i - 1) * (NU * NU * 16) + dl;
 #pragma unroll
@@ -883,12 +861,6 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     if (live && a == 0) status[d] = st;
     const bool bad = st != 0;
 
-    if constexpr (kEarly) {
-      __builtin_amdgcn_sched_barrier(0);
-      const int nx = next < ntiles ? next : ntiles - 1;
-      stage_load_asm(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
-    }
-
     // ---------------- backward sweep + recovery: registers + one G block per knot ----------------
     double un[NU], gq[NU][NU];
 #pragma unroll
@@ -899,7 +871,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     }
 #pragma unroll
     for (int i = MAXM - 1; i >= 0; --i) {
-      if (!kEarly && i == (MAXM >= 2 ? 1 : 0)) {
+      if (i == (MAXM >= 2 ? 1 : 0)) {
         // software pipelining across tiles: with two segments left most of this tile's registers
         // are dead, so the next tile's inputs start their trip from HBM now.  Unconditional
         // (clamped to the last tile) and at a static point of the unrolled loop: a conditional
@@ -927,12 +899,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
             for (int c = 0; c < NU; ++c) gq[r][c] = g[(r * NU + c) * 16];
         }
         double c[NC];
-#ifdef MSNAP_EXPERIMENT_STORE_ONLY
-#pragma unroll
-        for (int m = 0; m < NC; ++m) c[m] = u[m % NU] + wreg[i];
-#else
         recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], xreg[i], u, un, c);
-#endif
         if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
         if constexpr (NC == 8)
           store_segment_quad8(MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid, lane, c, bad);
@@ -962,7 +929,7 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 constexpr int kTwistDrones = 8;
 constexpr int kTwistFenceHalf = 9;   // instances with this many knots per side fence the scheduler per knot
 
-#ifdef MSNAP_EXPERIMENT_TIMELINE
+#ifdef MSNAP_TOOLS_TIMELINE
 // phase timestamps of the twisted kernel (s_memrealtime, 100 MHz, and s_memtime): tools/twist_timeline.py
 __device__ unsigned long long g_timeline[1024 * 32];
 #define MSNAP_TL(k)                                                                       \
@@ -1009,7 +976,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
   for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#ifdef MSNAP_EXPERIMENT_TIMELINE
+#ifdef MSNAP_TOOLS_TIMELINE
     const int tl_tile = tile;
 #endif
     MSNAP_TL(0);
@@ -1301,7 +1268,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     // instances do not care (order 7 M > 10) or lose 1-2 % (order 9 M <= 10) and keep the resident set.
     const bool oversubscribe = (K <= 4) == (M <= kRegMaxSeg);
     int grid = ctx->n_cu * (two_per_simd ? 8 : 4) * (oversubscribe ? 8 : 1);
-    if (const char *e = getenv("MSNAP_EXPERIMENT_REG_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+    if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;   // msnap_set_option: tests walk several tiles per wave
     if (grid > ntiles) grid = ntiles;
     if (M <= kRegMaxSeg)
       hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
@@ -1339,7 +1306,7 @@ bool solve_uses_global_scratch(const msnap_ctx *ctx, int n_seg) {
          kMaxLdsBytes;
 }
 
-#ifdef MSNAP_EXPERIMENT_TIMELINE
+#ifdef MSNAP_TOOLS_TIMELINE
 extern "C" int msnap_debug_read_timeline(unsigned long long *out, int n_words) {
   if (hipDeviceSynchronize() != hipSuccess) return MSNAP_EHIP;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n_words * 8) == hipSuccess ? MSNAP_OK : MSNAP_EHIP;

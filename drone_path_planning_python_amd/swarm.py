@@ -116,9 +116,16 @@ def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, t
 
 
 def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, rank: int, dt: float,
-                   n_samples: int, radius: float, dist=None, torch=None) -> FormationResult:
-    """Sample the local shard, exchange, collide own rows against everybody."""
+                   n_samples: int, radius: float, dist=None, torch=None, status_local=None) -> FormationResult:
+    """Sample the local shard, exchange, collide own rows against everybody.
+
+    `status_local` (the solve's per-drone status of this shard): a failed solve leaves NaN
+    coefficients, and NaN samples never win a minimum (include/msnap.h) -- such a drone would
+    read as collision-free and be invisible to the others, so it is refused here."""
     lo, hi = shard_bounds(n_total, world, rank)
+    if status_local is not None and int(abs(status_local).sum()) != 0:
+        raise ValueError("formation_pass: the solve reported failed drones (status != 0) in rows "
+                         f"[{lo}, {hi}); their samples are NaN and cannot be collision-checked")
     pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
     pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch) if world > 1 else pos_local
     md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)

@@ -75,6 +75,21 @@ int msnap_sync(msnap_ctx *ctx);
  * pinned ones let the copy engines read and write them directly). */
 int msnap_host_alloc(void **ptr, size_t bytes);
 int msnap_host_free(void *ptr);
+/* Launch-geometry options of a context (tests and tuning tools; every default is chosen per
+ * launch from the device's CU count).  Unknown names return MSNAP_EINVAL.
+ *   "solve_grid_waves"     cap on the persistent grid of the large-batch solve kernel (0 = default);
+ *                          a small cap makes every wave walk several tiles (the regime of a
+ *                          saturating batch) on a batch the oracle checks in seconds
+ *   "gemm_grid_waves"      the same for the shared-grid GEMM
+ *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
+ *   "no_twist"             1: small batches stay on the one-sided kernels
+ *   "collide_waves_per_cu" (row block, column slice) waves per CU of the pairwise pass (0 = 32)
+ *   "pipe_chunk_mb"        output megabytes per chunk of the chunked host-pointer solves
+ * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_COLLIDE_WAVES_PER_CU and
+ * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
+int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
+int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value);
 /* hipEvent timing on the context's stream (bench.py roofline leg). */
 int msnap_timer_start(msnap_ctx *ctx);
 int msnap_timer_stop(msnap_ctx *ctx, float *elapsed_ms);   /* synchronises */
@@ -175,6 +190,11 @@ int msnap_snap_cost_device(msnap_ctx *ctx, int n_drones, int n_seg, const double
  *   min_dist [n_rows]  min over other drones j != global row and samples of |p_i-p_j|
  *   partner  [n_rows]  lowest global j attaining it (-1 if none)
  *   hit      [n_rows]  min_dist < 2*radius
+ * n_cols == 0 gives (+inf, -1, 0).  n_rows <= 65535 * 64 per call.
+ * Non-finite samples never win a minimum (IEEE minNum): a drone whose samples are NaN -- the
+ * output of a solve with status != 0 -- reports (+inf, -1, 0) and is invisible to the other
+ * drones.  Check status[] of the solve before trusting a "no hit" (the Python pipeline,
+ * swarm.formation_pass, refuses such drones).  The same holds for msnap_mesh_sweep.
  */
 int msnap_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
                             int n_samples, const double *pos_rows, const double *pos_cols,

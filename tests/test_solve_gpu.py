@@ -61,7 +61,10 @@ def test_partial_tiles(ctx7, n):
 
 @pytest.mark.parametrize("m", [1, 2, 3, 5, 11, 12, 13, 14, 20, 37, 49])
 def test_segment_counts_register_and_lds_variants(ctx7, m):
-    """n_seg <= 12 runs solve_kernel_reg, 13.. the LDS-stash variant."""
+    """A 21-drone batch takes the small-batch two-sided kernel up to 24 segments and the rolled
+    LDS-stash kernel above; the register-resident throughput kernel is reached by
+    test_twisted_and_one_sided_kernels_agree (no_twist) and, in its multi-tile regime, by
+    test_persistent_solve_walks_several_tiles."""
     from drone_path_planning_python_amd.synthetic import swarm
     wp, t = swarm(12 + m, 21, m)
     coef, dur, status = ctx7.solve_batch(wp, t)
@@ -335,8 +338,8 @@ def test_twisted_and_one_sided_kernels_agree(order, m, monkeypatch):
     t[5] += 0.3                     # one drone with t[0] != 0 (quirk on the start side)
     with Context(order=order, max_segments=64) as ctx:
         c_tw, d_tw, s_tw = ctx.solve_batch(wp, t)
-    monkeypatch.setenv("MSNAP_NO_TWIST", "1")
     with Context(order=order, max_segments=64) as ctx:
+        ctx.set_option("no_twist", 1)
         c_os, d_os, s_os = ctx.solve_batch(wp, t)
     assert (s_tw == 0).all() and (s_os == 0).all()
     import msnap_oracle as O
@@ -445,9 +448,9 @@ def test_chunked_host_solve_is_bitwise_the_single_shot_solve(n, shared, monkeypa
     wp, t = swarm(900, n, M)
     if shared:
         t = np.ascontiguousarray(t[0])
-    monkeypatch.setenv("MSNAP_PIPE_CHUNK_MB", "1")     # 1 MB / 1536 B per drone < 4096 -> chunk = 4096 drones
-    monkeypatch.setenv("MSNAP_NO_TWIST", "1")          # chunks and whole batch on the same kernel variant
     with Context(order=7, max_segments=16) as ctx:
+        ctx.set_option("pipe_chunk_mb", 1)   # 1 MB / 1536 B per drone < 4096 -> chunk = 4096 drones
+        ctx.set_option("no_twist", 1)        # chunks and whole batch on the same kernel variant
         dev = torch.device("cuda:0")
         dwp, dt = torch.from_numpy(wp).to(dev), torch.from_numpy(t).to(dev)
         dcoef = torch.empty((n, M, 4, 8), dtype=torch.float64, device=dev)
@@ -531,3 +534,150 @@ def test_random_shapes_against_oracle(ctx7, ctx9, seed):
     err = norm_rel(coef, ref)
     assert err <= (TIGHT if order == 7 else TOL), (order, N, M, shared, err)
     np.testing.assert_array_equal(dur, rdur)
+
+
+# ---------------------------------------------------------------------------
+# the persistent throughput kernels in the regime bench.py's saturated legs time:
+# every wave walks SEVERAL tiles (cross-tile asm prefetch retired by a hand-counted
+# s_waitcnt vmcnt in solve_kernel_reg, the `rt += gridDim.x` loop of the shared-grid GEMMs)
+# ---------------------------------------------------------------------------
+def _solve_in_shards(ctx, wp, t, shard):
+    parts = []
+    for lo in range(0, wp.shape[0], shard):
+        tt = t if t.ndim == 1 else t[lo:lo + shard]
+        parts.append(ctx.solve_batch(wp[lo:lo + shard], tt))
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("order,m,waves", [(7, 10, 5), (7, 7, 3), (7, 20, 5), (7, 14, 4), (9, 10, 5), (9, 16, 3),
+                                           (9, 20, 4)])
+def test_persistent_solve_walks_several_tiles(order, m, waves, shared):
+    """solve_kernel_reg<4|5, 10|20> with a grid of `waves` wavefronts: 600-odd drones are 38 tiles,
+    so every wave walks 7-13 tiles and the last tile is partial.  The result must equal, bit for
+    bit, the same batch solved 16 drones (one tile, no prefetch) at a time, and match the C oracle."""
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    n = 16 * 37 + 9
+    wp, t = swarm(4000 + 10 * m + order, n, m, shared_times=shared)
+    if not shared:
+        t[3] += 0.2                                      # one drone with the t[0] != 0 quirk
+    with Context(order=order, max_segments=64) as ctx:
+        ctx.set_option("no_twist", 1)                   # keep every launch on solve_kernel_reg
+        one_tile = _solve_in_shards(ctx, wp, t, 16)      # grid = 1 wave, one tile: the prefetch never waits
+        ctx.set_option("solve_grid_waves", waves)
+        assert ctx.get_option("solve_grid_waves") == waves
+        multi = ctx.solve_batch(wp, t)
+        # a failing drone in the middle of a wave's sequence must not disturb its neighbours' tiles
+        wpb = wp.copy()
+        wpb[16 * 11 + 5, 2, 1] = np.nan
+        bad = ctx.solve_batch(wpb, t)
+    assert (multi[2] == 0).all()
+    for a, b in zip(multi, one_tile):
+        np.testing.assert_array_equal(a, b)
+    ref, rdur = _c_ref(wp, t, ncoef=order + 1)
+    assert norm_rel(multi[0], ref) <= (TIGHT if order == 7 else 1e-6)
+    np.testing.assert_array_equal(multi[1], rdur if rdur.ndim == 2 else np.broadcast_to(rdur, multi[1].shape))
+    keep = np.arange(n) != 16 * 11 + 5
+    assert bad[2][16 * 11 + 5] == 3 and np.isnan(bad[0][16 * 11 + 5]).all()
+    np.testing.assert_array_equal(bad[0][keep], multi[0][keep])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "m20"])
+def test_persistent_solve_goldens_multi_tile(golden, name):
+    """The reference's own outputs (cfg2: 64 x 10, m20: 8 x 20, tiled to several tiles per wave)
+    through solve_kernel_reg with two persistent waves."""
+    from drone_path_planning_python_amd import Context
+    wp, t, ref = golden[name + "_wp"], golden[name + "_t"], golden[name + "_coef"]
+    reps = 200 // wp.shape[0] + 1
+    wpx, tx, refx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1)), np.tile(ref, (reps, 1, 1, 1))
+    with Context(order=7, max_segments=64) as ctx:
+        ctx.set_option("no_twist", 1)
+        ctx.set_option("solve_grid_waves", 2)
+        coef, dur, status = ctx.solve_batch(wpx, tx)
+    assert (status == 0).all()
+    assert norm_rel(coef, refx) <= TIGHT
+    np.testing.assert_array_equal(dur, np.tile(golden[name + "_dur"], (reps, 1)))
+
+
+@pytest.mark.parametrize("order,m,waves", [(7, 10, 3), (7, 15, 5), (7, 1, 2), (9, 10, 3), (9, 12, 4),
+                                           (7, 20, 3), (7, 49, 2), (9, 20, 3), (7, 63, 3)])
+def test_persistent_grid_gemm_walks_several_tiles(order, m, waves):
+    """K2 with a grid of `waves` wavefronts (register-resident operator up to 15 / 12 segments,
+    streaming operator above): 523 drones are 131 row tiles incl. a partial one.  Bit-identical
+    to the same batch in 4-drone shards (one row tile per launch), and equal to the K1 solve and
+    the C oracle."""
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    n = 523
+    wp, t = swarm(4100 + 10 * m + order, n, m, shared_times=True)
+    with Context(order=order, max_segments=64) as ctx:
+        ctx.prepare_grid(t)
+        parts = [ctx.solve_grid(wp[lo:lo + 4]) for lo in range(0, n, 4)]
+        one_tile = tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+        ctx.set_option("gemm_grid_waves", waves)
+        multi = ctx.solve_grid(wp)
+        k1 = ctx.solve_batch(wp, t)
+    assert (multi[2] == 0).all()
+    for a, b in zip(multi, one_tile):
+        np.testing.assert_array_equal(a, b)
+    ref, rdur = _c_ref(wp, t, ncoef=order + 1)
+    tol = 1e-8 if order == 7 else 1e-6
+    assert norm_rel(multi[0], ref) <= tol
+    assert norm_rel(multi[0], k1[0]) <= (1e-9 if m <= 20 else 1e-7)
+    np.testing.assert_array_equal(multi[1], np.broadcast_to(rdur, multi[1].shape))
+
+
+def test_streaming_gemm_large_batch_row_groups(ctx7):
+    """>= 16384 drones take the 16-drones-per-wave (RT = 4) form of the streaming GEMM; 20 segments,
+    shared grid, partial last row group, a few persistent waves.  Checked against K1 on every
+    drone and against the C oracle on a sample."""
+    from drone_path_planning_python_amd.synthetic import swarm
+    n, m = 16384 + 37, 20
+    wp, t = swarm(4242, n, m, shared_times=True)
+    ctx7.prepare_grid(t)
+    try:
+        ctx7.set_option("gemm_grid_waves", 7)
+        coef, dur, status = ctx7.solve_grid(wp)
+    finally:
+        ctx7.set_option("gemm_grid_waves", 0)
+    k1, kd, _ = ctx7.solve_batch(wp, t)
+    assert (status == 0).all()
+    assert norm_rel(coef, k1) <= 1e-9
+    np.testing.assert_array_equal(dur, kd)
+    pick = np.r_[0:64, n - 64:n]
+    ref, _ = _c_ref(wp[pick], t)
+    assert norm_rel(coef[pick], ref) <= 1e-8
+
+
+def test_reference_live_shape_through_the_mfma_path(ctx7, golden):
+    """The reference's own workload: 50 poses -> 49 segments on the 10/n grid
+    (scripts/drones_pols_generator.py:44-46; RB_planning_sep_coll_check.py:164 interpolates 50
+    states).  golden path49 is the reference's output for such a path; it must come out of the
+    shared-grid GEMM (streaming variant), including when several identical drones share a launch."""
+    wp, t, ref = golden["path49_wp"], golden["path49_t"], golden["path49_coef"]
+    ctx7.prepare_grid(t)
+    for n in (1, 2, 9):
+        coef, dur, status = ctx7.solve_grid(np.tile(wp[None], (n, 1, 1)))
+        assert (status == 0).all()
+        assert norm_rel(coef, np.tile(ref[None], (n, 1, 1, 1))) <= 1e-7
+        np.testing.assert_array_equal(dur, np.tile(golden["path49_dur"][None], (n, 1)))
+    # more than 63 segments: no operator is built, the call is the K1 solve on the stored grid
+    from drone_path_planning_python_amd.synthetic import swarm
+    wpl, tl = swarm(4343, 5, 70, shared_times=True)
+    ctx7.prepare_grid(tl)
+    c, d, s = ctx7.solve_grid(wpl)
+    k, kd, _ = ctx7.solve_batch(wpl, tl)
+    np.testing.assert_array_equal(c, k)
+    np.testing.assert_array_equal(d, kd)
+
+
+def test_options_api(ctx7):
+    from drone_path_planning_python_amd import MsnapError
+    with pytest.raises(MsnapError):
+        ctx7.set_option("no_such_option", 1)
+    with pytest.raises(MsnapError):
+        ctx7.get_option("no_such_option")
+    for name in ("solve_grid_waves", "gemm_grid_waves", "twist_max_drones", "no_twist", "collide_waves_per_cu"):
+        assert ctx7.get_option(name) == 0
+    assert ctx7.get_option("pipe_chunk_mb") == 64

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the shared-grid GEMM kernel (K2) on the headline shape; needs a library built
-with -DMSNAP_EXPERIMENT_TIMELINE (MSNAP_LIB_PATH)."""
+with -DMSNAP_TOOLS_TIMELINE (MSNAP_LIB_PATH)."""
 import ctypes
 import os
 import sys

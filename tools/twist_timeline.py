@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the small-batch (twisted) solve kernel on the headline shape.
-Needs a library built with -DMSNAP_EXPERIMENT_TIMELINE (MSNAP_LIB_PATH points at it):
+Needs a library built with -DMSNAP_TOOLS_TIMELINE (MSNAP_LIB_PATH points at it):
 each wave records s_memrealtime (100 MHz) and s_memtime at 5 points."""
 import ctypes
 import os
