@@ -5,21 +5,38 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (libmsnap's solve kernel, K1) over one
-batch of synthetic input: BASELINE.json configs[1], 256 drones x 10 segments,
-order 7, seeded random waypoints, per-drone random time grids (the general case:
-nothing is shared or precomputed between drones).  Inputs and outputs live in
-HBM (torch tensors are only the allocator); every rank solves its own 256-drone
-shard (weak scaling, no data-path collective: the solve shards by drone).
+Headline (`value`, `roofline`): a "step" is one pass of the hot path (libmsnap's solve kernel, K1)
+over one batch of synthetic input: BASELINE.json configs[1], 256 drones x 10 segments, order 7,
+seeded random waypoints, per-drone random time grids (the general case: nothing is shared or
+precomputed between drones).  Inputs and outputs live in HBM (torch tensors are only the
+allocator); every rank solves its own 256-drone batch (weak scaling, no data-path collective:
+the solve shards by drone).  K steps are captured in one hipGraph and replayed between
+barrier + synchronize brackets.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     HBM roofline of the solve kernel at the headline workload
                (algorithmic bytes: SURVEY.md 8d, 3080 B/trajectory at M=10,p=7)
-  cpu_baseline the C restatement of the reference algorithm (oracle/, "port")
-               timed on this box's host cores on a bounded sample
-  saturated    the same kernel on a batch large enough to fill the chip
-               (2^20 drones), with its own roofline fraction -- the 256-drone
-               headline is launch/latency-bound by construction
+  cpu_baseline the C restatement of the reference algorithm (oracle/, "port") timed on this
+               box's host cores on a bounded sample: B0 (one dense LU per axis, as the
+               reference) and B1 (one LU for the four right-hand sides), one thread and all cores
+  configs      every BASELINE.json config on this many GPUs, each with per-stage microseconds
+               (HIP events on the launching stream, max over ranks), roofline fraction and bound:
+                 [1] 256 x 10 (the headline again)
+                 [2] 4096 x 10: solve -> sample -> all-gather -> pairwise formation pass
+                 [3] 4096 x 20: the same + sweep against resources/stl/env-scene-hole.stl and
+                     env-scene-ltu-experiment.stl
+                 [4] 65536 x 10, order 9
+               For N > 1 configs [2]-[4] are SHARDED by drone over the ranks (strong scaling)
+               and the RCCL all_gather_into_tensor of the sampled positions is inside the timed
+               region.  [2]/[3] run on the formation-like inputs pinned by
+               tests/golden/formation_golden.npz and report their hit counts beside the
+               fixture's.
+  saturated    the solve kernel on a batch large enough to fill the chip (2^20 drones), with its
+               own roofline fraction and the parity of its first and last 4096 drones against
+               the C oracle -- the 256-drone headline is launch/latency-bound by construction
+  shared_grid  the reference's own usage (every drone on one uniform grid): K2, fp64 MFMA GEMM
+  end_to_end   configs[1] through the host-pointer entry point with page-locked arrays
+               (H2D + kernel + D2H per call); PCIe-inclusive, never `value`
 """
 from __future__ import annotations
 
@@ -39,11 +56,23 @@ if ROOT not in sys.path:
 METRIC = "minimum-snap trajectories/sec (N drones × M segments, order 7) at 1/2/4/8 MI355X"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s copy-achievable)
 HBM_COPY_GBS = 6290.0
+# fp64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (= 78.6 TFLOP/s of FMA / 2)
+VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
+XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
+PAIR_OPS = 9                   # 3 differences, 3 products, 2 sums, 1 minimum per pair and sample
+# instructions per point-triangle test on the face-region path of mesh_sweep_kernel (counted in the
+# ISA); vertex / edge regions exit earlier, so this prices every test at the longest path
+MESH_TEST_OPS = 104
 
 
 def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
     """in = 8*5*(M+1) (x,y,z,yaw,t), out = 8*M*(1 + 4*(p+1))."""
     return n_drones * (8 * 5 * (n_seg + 1) + 8 * n_seg * (1 + 4 * (order + 1)))
+
+
+def sampler_bytes(n_drones: int, n_seg: int, order: int, n_samples: int) -> int:
+    """K4: reads the x, y, z rows and the durations, writes [S][3] positions."""
+    return n_drones * 8 * (n_seg * (3 * (order + 1) + 1) + 3 * n_samples)
 
 
 def pmc_traffic(n_drones: int, n_seg: int, order: int):
@@ -71,6 +100,17 @@ def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) ->
     return "msnap::solve_kernel<%d, false>" % k
 
 
+def grid_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
+    """Which K2 variant libmsnap launches (mirror of launch_solve_grid in csrc/msnap_grid.hip)."""
+    nc = order + 1
+    nks = (n_seg + 4) // 4
+    if (n_seg * nc + 15) // 16 <= 8 and nks <= 4:
+        return "msnap::grid_gemm_kernel<%d, %d>" % (nc, n_seg)
+    if nks <= 16:
+        return "msnap::grid_gemm_stream_kernel<%d, %d, %d>" % (nc, nks, 4 if n_drones >= 64 * n_cu else 1)
+    return solve_kernel_name(n_drones, n_seg, order, n_cu)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,12 +124,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-saturated", action="store_true")
     ap.add_argument("--no-shared-grid", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-config pipelines")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--saturated-drones", type=int, default=1 << 20)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--config-reps", type=int, default=0, help="timed repetitions per config pipeline (0: from --steps)")
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--force-pg", action="store_true", help="initialise the process group even for one rank (rehearsal)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse N > 1 on a 1-GPU box "
-                         "(ranks then share device local_rank %% device_count)")
+                         "(ranks then share device local_rank %% device_count, the all-gather runs on host copies)")
     return ap.parse_args()
 
 
@@ -181,55 +224,303 @@ def timed_steps(torch, dist, batch, ctx, steps, warmup, use_graph, world):
     return wall, dev_ms
 
 
-def python_restatement_rate(wp, t, order, n=24):
-    """Calibration only: the NumPy restatement that follows the reference step for step
-    (oracle/msnap_oracle.py, dense assembly + np.linalg.solve per axis, bit-identical to the
-    reference), single core -- the reference itself measures ~100 trajectories/s."""
-    import msnap_oracle
-    t0 = time.perf_counter()
-    msnap_oracle.solve_batch(wp[:n], t[:n], ncoef=order + 1)
-    return n / (time.perf_counter() - t0)
+# ------------------------------------------------------------------------------------------
+# CPU baseline (oracle/, checker code: timed here, never on the product path)
+# ------------------------------------------------------------------------------------------
+def host_core_count() -> int:
+    """Cores this job may use: the affinity mask, capped by a cgroup CPU quota when one is set."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(float(parts[0]) / float(parts[1]) + 0.5)))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        n = min(n, max(1, int(q / int(g.read()) + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
 
 
 def cpu_baseline(n_seg, order, seconds):
-    """C restatement of the reference algorithm (oracle/msnap_oracle.c, one dense
-    LU with partial pivoting per axis like calculate_trajectory4D) on the host
-    cores, bounded to ~`seconds` of wall time."""
+    """C restatement of the reference algorithm (oracle/msnap_oracle.c) on the host cores, bounded to
+    ~`seconds` of wall time in all: B0 = one dense LU with partial pivoting per axis like
+    calculate_trajectory4D (the `value`), B1 = one LU for the four right-hand sides; each on all cores
+    this job may use and on one thread.  Plus the NumPy restatements on one core (calibration: the
+    reference itself measures ~100 trajectories/s)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle
+    import msnap_oracle
     from drone_path_planning_python_amd.synthetic import swarm
-    # the box gives one GPU a 16-core share of the host; never oversubscribe it
-    threads = max(1, min(c_oracle.max_threads(), os.cpu_count() or 1, 16))
+    threads = max(1, min(c_oracle.max_threads(), host_core_count()))
     wp, t = swarm(2, 256, n_seg)
-    # calibrate on ~1 s of work, then size the sample to ~`seconds`
-    reps = 8
-    while True:
+
+    def rate(faithful, n_threads, budget):
+        reps, probe = 2, 0.0
+        while True:     # calibrate, then size the sample to the budget
+            wpx, tx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1))
+            t0 = time.perf_counter()
+            c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=faithful, n_threads=n_threads)
+            probe = time.perf_counter() - t0
+            if probe > 0.25 or reps >= 1 << 14:
+                break
+            reps *= 4
+        reps = int(max(1, min(1 << 16, reps * budget / probe)))
         wpx, tx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1))
         t0 = time.perf_counter()
-        c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=True, n_threads=threads)
-        probe = time.perf_counter() - t0
-        if probe > 0.5 or reps >= 1 << 14:
-            break
-        reps *= 4
-    reps = int(max(reps, min(1 << 16, reps * seconds / probe)))
-    n = 256 * reps
-    wpx, tx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1))
+        _, _, _, used = c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=faithful, n_threads=n_threads)
+        dt = time.perf_counter() - t0
+        return 256 * reps / dt, 256 * reps, int(used), dt
+
+    b0_all, n0, used, dt0 = rate(True, threads, 0.45 * seconds)
+    b1_all, n1, _, dt1 = rate(False, threads, 0.2 * seconds)
+    b0_one, _, _, _ = rate(True, 1, 0.12 * seconds)
+    b1_one, _, _, _ = rate(False, 1, 0.08 * seconds)
     t0 = time.perf_counter()
-    _, _, info, used = c_oracle.solve_batch(wpx, tx, ncoef=order + 1, faithful=True, n_threads=threads)
-    dt = time.perf_counter() - t0
-    n1 = 256 * max(1, reps // (4 * threads))
-    t1 = time.perf_counter()
-    c_oracle.solve_batch(wpx[:n1], tx[:n1], ncoef=order + 1, faithful=True, n_threads=1)
-    dt1 = time.perf_counter() - t1
+    msnap_oracle.solve_batch(wp[:24], t[:24], ncoef=order + 1)
+    np_b0 = 24 / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    msnap_oracle.solve_batch_fast(wp, t, ncoef=order + 1)
+    np_b1 = 256 / (time.perf_counter() - t0)
+    n = (order + 1) * n_seg
     return {
-        "value": n / dt, "unit": "trajectories/s", "cores": int(used), "kind": "port",
-        "sample": f"{n} trajectories ({reps} x the 256-drone x {n_seg}-segment batch), dense "
-                  f"{(order + 1) * n_seg}x{(order + 1) * n_seg} LU with partial pivoting per axis "
-                  f"(C restatement of the reference algorithm), OpenMP over drones, {dt:.1f} s",
-        "single_thread_value": n1 / dt1,
+        "value": b0_all, "unit": "trajectories/s", "cores": used, "kind": "port",
+        "sample": f"B0: {n0} trajectories (copies of the 256-drone x {n_seg}-segment batch), one dense {n}x{n} LU "
+                  f"with partial pivoting per axis (C restatement of the reference algorithm), OpenMP over drones "
+                  f"on all {used} cores this job may use, {dt0:.1f} s; B1: {n1} trajectories, {dt1:.1f} s",
+        "single_thread_value": b0_one,
+        "b1_one_lu_four_rhs": {"value": b1_all, "cores": used, "single_thread_value": b1_one},
+        "numpy_restatement_single_core": {"b0_reference_faithful": np_b0, "b1_vectorised_batched_solve": np_b1},
         "host_cpus": os.cpu_count(),
-        "python_restatement_single_core": python_restatement_rate(wp, t, order),
     }
+
+
+def oracle_parity(coef_dev, wp, t, order, idx):
+    """max norm-relative error of the device coefficients of drones `idx` against the C oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle
+    tt = t if t.ndim == 1 else t[idx]
+    ref, _, info, _ = c_oracle.solve_batch(wp[idx], tt, ncoef=order + 1, faithful=False, n_threads=0)
+    got = coef_dev[idx].cpu().numpy()
+    num = np.abs(got - ref).max(axis=(1, 3))
+    den = np.abs(ref).max(axis=(1, 3))
+    return float((num / np.where(den == 0, 1.0, den)).max()), bool(info.any())
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json configs[2..4]: pipelines sharded by drone over the ranks
+# ------------------------------------------------------------------------------------------
+class HostGather:
+    """gloo rehearsal only: the collective on host copies of the position blocks."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_gather_into_tensor(self, out, inp):
+        o, i = out.cpu(), inp.cpu()
+        self.dist.all_gather_into_tensor(o, i)
+        out.copy_(o)
+
+
+def max_over_ranks(torch, dist, values, device, use_pg):
+    tv = torch.tensor(values, dtype=torch.float64, device=device)
+    if use_pg:
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+    return [float(x) for x in tv.tolist()]
+
+
+def sum_over_ranks(torch, dist, values, device, use_pg):
+    tv = torch.tensor(values, dtype=torch.int64, device=device)
+    if use_pg:
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+    return [int(x) for x in tv.tolist()]
+
+
+def run_formation_config(cfg, env, reps, warm):
+    """configs[2] (cfg = 2) / configs[3] (cfg = 3): solve -> sample -> all-gather -> pairwise pass
+    (-> mesh sweep), 4096 drones sharded by drone.  Returns the report dict (rank 0) or None."""
+    torch, dist, ctx, device = env["torch"], env["dist"], env["ctx7"], env["device"]
+    rank, world, use_pg, coll, red_dev = env["rank"], env["world"], env["use_pg"], env["coll"], env["red_dev"]
+    from drone_path_planning_python_amd import stl, swarm, synthetic
+    rb, off, t = synthetic.formation_config(cfg)
+    G, m, _ = rb.shape
+    M, N, order = m - 1, G * off.shape[0], 7
+    # inputs through a8 on the GPU (untimed: the producer of the waypoints, not the path being timed)
+    wp = synthetic.formation_waypoints(ctx.formation_transform(rb.reshape(G * m, 7), off), G)
+    lo, hi = swarm.shard_bounds(N, world, rank)
+    n = hi - lo
+    S = synthetic.formation_sample_count(t)
+    comp = swarm.DeviceCompute(ctx, torch)
+    twp = torch.from_numpy(np.ascontiguousarray(wp[lo:hi])).to(device)
+    tt = torch.from_numpy(t).to(device)
+    tris = None
+    if cfg == 3:
+        gd = os.path.join(ROOT, "tests", "golden")    # the reference's resources/stl files, copied as data
+        tris = torch.from_numpy(np.concatenate([stl.load_stl(os.path.join(gd, "env-scene-hole.stl")),
+                                                stl.load_stl(os.path.join(gd, "env-scene-ltu-experiment.stl"))])
+                                ).to(device)
+    stage_names = ["solve", "sample", "allgather", "pairwise"] + (["mesh"] if cfg == 3 else [])
+    nst = len(stage_names)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
+
+    def one(rec):
+        if rec:
+            rec[0].record()
+        coef, dur, status = comp.solve(twp, tt)
+        if rec:
+            rec[1].record()
+        pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
+        if rec:
+            rec[2].record()
+        pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch) if world > 1 else pos
+        if rec:
+            rec[3].record()
+        md, partner, hit = comp.collide(pos, lo, pos_all, synthetic.DRONE_RADIUS)
+        if rec:
+            rec[4].record()
+        mh = None
+        if tris is not None:
+            _, mh = comp.mesh(pos, tris, synthetic.DRONE_RADIUS)
+            if rec:
+                rec[5].record()
+        return status, hit, mh, md
+
+    for _ in range(warm):
+        one(None)
+    torch.cuda.synchronize()
+    if use_pg:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        status, hit, mh, md = one(ev[r])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if use_pg:
+        dist.barrier()
+    stage_us = [sum(ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)) / reps * 1e3 for k in range(nst)]
+    # the shared-grid GEMM on the same shard, outside the pipeline (the inputs are on the reference's uniform grid)
+    ctx.prepare_grid(t)
+    gcoef = torch.empty((n, M, 4, 8), dtype=torch.float64, device=device)
+    gdur = torch.empty((n, M), dtype=torch.float64, device=device)
+    gst = torch.empty((n,), dtype=torch.int32, device=device)
+    for _ in range(3):
+        ctx.solve_grid_device(n, twp, gcoef, gdur, gst)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ctx.solve_grid_device(n, twp, gcoef, gdur, gst)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_us = e0.elapsed_time(e1) / reps * 1e3
+    mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us], red_dev, use_pg)
+    cnt = sum_over_ranks(torch, dist, [int(status.abs().sum().item()), int(hit.sum().item()),
+                                       int(mh.sum().item()) if mh is not None else 0], red_dev, use_pg)
+    if rank != 0:
+        return None
+    wall_max, st, gemm = mx[0], dict(zip(stage_names, mx[1:1 + nst])), mx[1 + nst]
+    per = wall_max / reps
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz"))
+    n_max = max(swarm.shard_sizes(N, world))
+    pair_alg = N * (N - 1) / 2 * S * PAIR_OPS                 # SURVEY.md 8d: every unordered pair once
+    pair_exec = n_max * N * S * PAIR_OPS                       # what the largest shard evaluates
+    rep = {
+        "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
+                    f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
+                    f"{synthetic.SAMPLE_DT} s" + (f", {tris.shape[0]}-triangle scene (env-scene-hole.stl + "
+                                                   f"env-scene-ltu-experiment.stl)" if tris is not None else ""),
+        "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling)", "rccl_ranks": world,
+        "reps": reps, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
+        "stage_us": st,
+        "solve_failures": cnt[0], "pairwise_hits": cnt[1], "pairwise_hits_fixture": int(fix[f"cfg{cfg}_pair_hit_idx"].size),
+        "stages": {
+            "solve": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm",
+                      "frac": algorithmic_bytes(n_max, M, order) / (st["solve"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "solve_shared_grid_gemm": {"kernel": grid_kernel_name(n_max, M, order), "bound": "hbm", "us": gemm,
+                                       "frac": algorithmic_bytes(n_max, M, order) / (gemm * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "note": "same shard through K2, outside the pipeline time"},
+            "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
+                       "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "allgather": {"bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24 if world > 1 else 0,
+                          "frac": ((N - n_max) * S * 24 / (st["allgather"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS))
+                          if world > 1 and st["allgather"] > 0 else None},
+            "pairwise": {"kernel": "msnap::collide_partial_kernel + collide_merge_kernel", "bound": "valu_f64",
+                         "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
+                         "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
+                         "note": "frac counts each unordered pair once (N(N-1)/2 x S x 9 operations, SURVEY.md 8d), "
+                                 "per GPU; frac_executed counts the pair-samples the kernel evaluates"},
+        },
+    }
+    if cfg == 3:
+        rep["mesh_hits"] = cnt[2]
+        rep["mesh_hits_fixture"] = int(fix["cfg3_mesh_hit_idx"].size)
+        tests = n_max * S * int(tris.shape[0])
+        rep["stages"]["mesh"] = {"kernel": "msnap::mesh_sweep_kernel", "bound": "valu_f64",
+                                 "point_triangle_tests_per_s": tests / (st["mesh"] * 1e-6),
+                                 "frac": tests * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
+                                 "note": f"{MESH_TEST_OPS} fp64 operations per test (face-region path, every test "
+                                         "priced at the longest path; tests culled by the segment bounds count as done)"}
+    return rep
+
+
+def run_solve_config(env, N, M, order, reps, warm, label):
+    """configs[4]: N drones x M segments sharded by drone, solve only."""
+    torch, dist, device = env["torch"], env["dist"], env["device"]
+    rank, world, use_pg, red_dev = env["rank"], env["world"], env["use_pg"], env["red_dev"]
+    from drone_path_planning_python_amd import swarm
+    from drone_path_planning_python_amd.synthetic import swarm as synth
+    ctx = env["ctx9"] if order == 9 else env["ctx7"]
+    lo, hi = swarm.shard_bounds(N, world, rank)
+    wp, t = synth(5, N, M)                        # every rank builds the same swarm and keeps its shard
+    batch = DeviceBatch(torch, ctx, wp[lo:hi], t[lo:hi], M, order, device)
+    wall, dev_ms = timed_steps(torch, dist, batch, ctx, reps, warm, False, world if use_pg else 1)
+    fails = int(batch.status.abs().sum().item())
+    pick = np.r_[0:min(256, hi - lo), max(0, hi - lo - 256):hi - lo]
+    err, bad = oracle_parity(batch.coef, wp[lo:hi], t[lo:hi], order, pick)
+    mx = max_over_ranks(torch, dist, [wall, dev_ms, err], red_dev, use_pg)
+    cnt = sum_over_ranks(torch, dist, [fails], red_dev, use_pg)
+    if rank != 0:
+        return None
+    n_max = max(swarm.shard_sizes(N, world))
+    per, kus = mx[0] / reps, mx[1] / reps * 1e3
+    return {
+        "workload": f"{label}: {N} drones x {M} segments, order {order}, per-drone random time grids",
+        "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling, no collective)",
+        "reps": reps, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
+        "stage_us": {"solve": kus}, "solve_failures": cnt[0], "max_norm_rel_err_vs_oracle": mx[2],
+        "stages": {"solve": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm",
+                             "frac": algorithmic_bytes(n_max, M, order) / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS}},
+    }
+
+
+def end_to_end(ctx, wp, t, order, calls=60):
+    """configs[1] through msnap_solve_batch with page-locked host arrays: H2D + kernel + D2H per call."""
+    from drone_path_planning_python_amd import pinned_empty
+    n, m, _ = wp.shape
+    pwp, pt = pinned_empty(wp.shape), pinned_empty(t.shape)
+    pwp[...] = wp
+    pt[...] = t
+    out = (pinned_empty((n, m - 1, 4, order + 1)), pinned_empty((n, m - 1)), pinned_empty((n,), np.int32))
+    for _ in range(5):
+        ctx.solve_batch(pwp, pt, out=out)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        ctx.solve_batch(pwp, pt, out=out)
+    per = (time.perf_counter() - t0) / calls
+    assert not out[2].any()
+    moved = wp.nbytes + t.nbytes + sum(a.nbytes for a in out)
+    return {"value": n / per, "unit": "trajectories/s", "us_per_call": per * 1e6, "calls": calls,
+            "host_link_GBps": moved / per / 1e9,
+            "what": "msnap_solve_batch (host pointers, page-locked): upload, kernel, download, synchronise per call"}
 
 
 def main():
@@ -252,6 +543,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)   # RCCL
         else:
             dist.init_process_group(backend="gloo")
+    red_dev = device if args.backend == "nccl" else "cpu"
 
     from drone_path_planning_python_amd import Context
     from drone_path_planning_python_amd.synthetic import swarm
@@ -265,11 +557,28 @@ def main():
     use_graph = not args.no_graph
     wall, dev_ms = timed_steps(torch, dist, batch, ctx, args.steps, args.warmup, use_graph, world)
     assert int(batch.status.abs().sum().item()) == 0, "solve reported per-drone failures"
+    head_err, _ = oracle_parity(batch.coef, wp, t, order, np.arange(args.drones))
+    wall_max, dev_ms_max, head_err = max_over_ranks(torch, dist, [wall, dev_ms, head_err], red_dev, use_pg)
 
-    times = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-    if use_pg:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    wall_max, dev_ms_max = float(times[0].item()), float(times[1].item())
+    # ---- BASELINE.json configs[2..4] on all ranks (sharded), with the RCCL all-gather timed ----
+    configs = None
+    if not args.no_configs:
+        reps = args.config_reps or max(10, min(args.steps, 50))
+        ctx7 = ctx if order == 7 else Context(device_id=dev_index, order=7, max_segments=64)
+        ctx9 = ctx if order == 9 else Context(device_id=dev_index, order=9, max_segments=64)
+        for c in (ctx7, ctx9):
+            c.set_stream(torch.cuda.current_stream().cuda_stream)
+        env = dict(torch=torch, dist=dist, ctx7=ctx7, ctx9=ctx9, device=device, rank=rank, world=world,
+                   use_pg=use_pg, red_dev=red_dev,
+                   coll=dist if args.backend == "nccl" else HostGather(dist))
+        c2 = run_formation_config(2, env, reps, 5)
+        c3 = run_formation_config(3, env, reps, 5)
+        c4 = run_solve_config(env, 65536, 10, 9, reps, 10, "configs[4]")
+        configs = {"2": c2, "3": c3, "4": c4}
+        for c in (ctx7, ctx9):
+            if c is not ctx:
+                c.use_own_stream()
+                c.close()
 
     sat = None
     if rank == 0 and not args.no_saturated:
@@ -278,22 +587,33 @@ def main():
         reps = (nbig + 4095) // 4096
         wpb = np.tile(wpb, (reps, 1, 1))[:nbig]
         tb = tb if tb.ndim == 1 else np.tile(tb, (reps, 1))[:nbig]
+        # the two ends of the batch get their own inputs, so a tile that read a neighbour's (or a stale
+        # prefetch's) waypoints cannot pass as its periodic twin
+        wpe, te = swarm(12, 8192, M, shared_times=args.shared_times)
+        wpb[:4096], wpb[-4096:] = wpe[:4096], wpe[4096:]
+        if tb.ndim == 2:
+            tb[:4096], tb[-4096:] = te[:4096], te[4096:]
         big = DeviceBatch(torch, ctx, wpb, tb, M, order, device)
         # ~30 ms of sustained load before timing: the GPU's clocks settle over the first ~40 launches
         # (0.82 -> 0.68 ms per launch, tools/sat_ramp.py); the headline leg is warmed by its own replays
         ksat, wsat = 40, 40
         _, sat_ms = timed_steps(torch, dist, big, ctx, ksat, wsat, False, 1)
         assert int(big.status.abs().sum().item()) == 0
+        # parity of what was just timed (every wave walked several tiles): both ends against the C oracle
+        ends = np.r_[0:4096, nbig - 4096:nbig]
+        sat_err, sat_bad = oracle_parity(big.coef, wpb, tb, order, ends)
         per = sat_ms / ksat * 1e-3
         b = algorithmic_bytes(nbig, M, order)
         sat = {
             "workload": f"{nbig} drones x {M} segments, order {order}, one launch",
             "value": nbig / per, "unit": "trajectories/s", "ms_per_launch": per * 1e3,
+            "max_norm_rel_err_vs_oracle": sat_err, "parity_sample": "first and last 4096 drones of the timed output",
             "roofline": {"bound": "hbm", "achieved": b / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b / per / 1e9 / HBM_PEAK_GBS, "frac_of_copy_achievable": b / per / 1e9 / HBM_COPY_GBS,
                          "kernel": solve_kernel_name(nbig, M, order),
                          "traffic": pmc_traffic(nbig, M, order)[0]},
         }
+        assert sat_err <= 1e-6 and not sat_bad, f"saturated leg parity {sat_err:.3e}"
         del big
 
     # the reference's own usage pattern: every drone on one shared uniform grid -> K2
@@ -308,23 +628,34 @@ def main():
         assert int(gsmall.status.abs().sum().item()) == 0
         nbig = args.saturated_drones
         wpb = np.tile(wps, ((nbig + args.drones - 1) // args.drones, 1, 1))[:nbig]
+        wpe, _ = swarm(13, 8192, M, shared_times=True)
+        wpb[:4096], wpb[-4096:] = wpe[:4096], wpe[4096:]
         gbig = GridBatch(torch, ctx, wpb, M, order, device)
         _, gb_ms = timed_steps(torch, dist, gbig, ctx, 40, 40, False, 1)
+        g_err, g_bad = oracle_parity(gbig.coef, wpb, ts, order, np.r_[0:4096, nbig - 4096:nbig])
+        assert g_err <= 1e-6 and not g_bad, f"shared-grid saturated leg parity {g_err:.3e}"
         per_s, per_b = g_ms / args.steps * 1e-3, gb_ms / 40 * 1e-3
         bs, bb = algorithmic_bytes(args.drones, M, order), algorithmic_bytes(nbig, M, order)
         grid = {
             "workload": f"shared uniform time grid t_i = i*10/(M+1) (scripts/drones_pols_generator.py:44-46), "
                         f"operator prepared once, K2 fp64 MFMA GEMM per step",
-            "kernel": "msnap::grid_gemm_kernel<%d, %d>" % (order + 1, M),
+            "kernel": grid_kernel_name(args.drones, M, order),
             "headline_shape": {"drones": args.drones, "value": args.drones / per_s, "us_per_step": per_s * 1e6,
                                "roofline_frac": bs / per_s / 1e9 / HBM_PEAK_GBS},
             "saturated": {"drones": nbig, "value": nbig / per_b, "ms_per_launch": per_b * 1e3,
-                          "achieved_GBps": bb / per_b / 1e9, "roofline_frac": bb / per_b / 1e9 / HBM_PEAK_GBS},
+                          "achieved_GBps": bb / per_b / 1e9, "roofline_frac": bb / per_b / 1e9 / HBM_PEAK_GBS,
+                          "max_norm_rel_err_vs_oracle": g_err},
         }
         del gbig, gsmall
 
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        ctx.use_own_stream()
+        e2e = end_to_end(ctx, wp, t, order)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(M, order, args.cpu_seconds)
 
     if use_pg:
@@ -335,6 +666,25 @@ def main():
         bytes_launch = algorithmic_bytes(args.drones, M, order)
         kname = solve_kernel_name(args.drones, M, order)
         traffic = pmc_traffic(args.drones, M, order)[0]
+        roof = {
+            "bound": "hbm",
+            "kernel": kname,
+            "achieved": bytes_launch / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_launch,
+            "avg_launch_us": per_launch_s * 1e6,
+            "note": "256 drones are 788 KB: 0.1 us of HBM time under a launch floor of ~2.5 us, so this config "
+                    "cannot exceed ~4 % by construction; configs[4] and `saturated` show the same kernel family "
+                    "where the batch fills the chip",
+        }
+        if configs is not None:
+            configs = {"1": {"workload": f"configs[1]: {args.drones} drones x {M} segments, order {order} "
+                                         "(the headline; per GPU, weak scaling)",
+                             "value": total / wall_max, "unit": "trajectories/s",
+                             "stage_us": {"solve": per_launch_s * 1e6}, "max_norm_rel_err_vs_oracle": head_err,
+                             "stages": {"solve": {"kernel": kname, "bound": "hbm (launch-bound at this size)",
+                                                  "frac": roof["frac"]}}}, **configs}
         line = {
             "metric": METRIC,
             "value": total / wall_max,
@@ -356,18 +706,13 @@ def main():
                 "parallelism": f"drone-sharded x{world}, no data-path collective",
                 "launch": "hipGraph of K steps" if use_graph else "eager",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kname,
-                "achieved": bytes_launch / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": bytes_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_launch,
-                "avg_launch_us": per_launch_s * 1e6,
-            },
+            "max_norm_rel_err_vs_oracle": head_err,
+            "roofline": roof,
             "cpu_baseline": cpu,
+            "configs": configs,
             "saturated": sat,
             "shared_grid": grid,
+            "end_to_end": e2e,
         }
         print(json.dumps(line), flush=True)
     ctx.close()

@@ -105,12 +105,14 @@ def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, t
         return pos_local
     S = pos_local.shape[1]
     nmax = max(sizes)
+    gathered = torch.empty((world * nmax, S, 3), dtype=pos_local.dtype, device=pos_local.device)
+    if all(s == nmax for s in sizes):
+        # even shards (4096 drones on 2, 4 or 8 GPUs): the shard itself is the send buffer
+        dist.all_gather_into_tensor(gathered, pos_local.contiguous())
+        return gathered
     padded = torch.zeros((nmax, S, 3), dtype=pos_local.dtype, device=pos_local.device)
     padded[:pos_local.shape[0]] = pos_local
-    gathered = torch.empty((world * nmax, S, 3), dtype=pos_local.dtype, device=pos_local.device)
     dist.all_gather_into_tensor(gathered, padded)
-    if all(s == nmax for s in sizes):
-        return gathered
     parts = [gathered[r * nmax:r * nmax + sizes[r]] for r in range(world)]
     return torch.cat(parts, dim=0)
 

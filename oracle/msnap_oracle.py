@@ -434,17 +434,22 @@ def snap_cost(coef: np.ndarray, dur: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------
 def formation_collide(pos: np.ndarray, radius: float):
     """pos [N,S,3] -> (min_dist [N] over other drones and samples, partner [N],
-    hit [N] bool: min_dist < 2r).  partner = lowest index attaining the min."""
+    hit [N] bool: min_dist < 2r).  partner = lowest index attaining the min.
+    Squared distances are (dx*dx + dy*dy) + dz*dz, each operation rounded separately;
+    NaN samples never win a minimum (include/msnap.h)."""
     N = pos.shape[0]
     mind = np.full(N, np.inf)
     partner = np.full(N, -1, dtype=np.int32)
     for i in range(N):
         d = pos - pos[i][None, :, :]
-        d2 = np.einsum('nsk,nsk->ns', d, d).min(axis=1)
+        sq = d * d
+        d2 = np.fmin.reduce((sq[..., 0] + sq[..., 1]) + sq[..., 2], axis=1)
+        d2 = np.where(np.isnan(d2), np.inf, d2)
         d2[i] = np.inf
         j = int(np.argmin(d2))
-        mind[i] = math.sqrt(d2[j]) if N > 1 else np.inf
-        partner[i] = j if N > 1 else -1
+        if N > 1 and d2[j] < np.inf:
+            mind[i] = math.sqrt(d2[j])
+            partner[i] = j
     return mind, partner, mind < 2.0 * radius
 
 

@@ -1,0 +1,155 @@
+"""BASELINE.json configs[2] / configs[3] at full size (4096 drones), pinned end to end by
+tests/golden/formation_golden.npz (tests/golden/make_formation_golden.py): formation-like
+inputs through a8, solve, sample, pairwise pass, sweep against the reference's STL obstacles.
+
+not gpu:  the oracle pipeline reproduces the fixture (so the fixture pins the oracle too);
+gpu:      the HIP pipeline through the C-ABI gives the same hit sets, partners and distances.
+The collision passes have no reference implementation (parity unpinned): the
+fixture holds this repo's definition evaluated by the CPU oracle; the coefficients of every
+128th drone in it were computed by the reference itself.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import c_oracle
+import msnap_oracle as O
+from conftest import GOLDEN_DIR, norm_rel
+from drone_path_planning_python_amd import stl, synthetic
+
+TIGHT = 1e-9
+
+
+@pytest.fixture(scope="module")
+def fgold():
+    return np.load(os.path.join(GOLDEN_DIR, "formation_golden.npz"))
+
+
+def _scene():
+    return np.concatenate([stl.load_stl(os.path.join(GOLDEN_DIR, "env-scene-hole.stl")),
+                           stl.load_stl(os.path.join(GOLDEN_DIR, "env-scene-ltu-experiment.stl"))])
+
+
+def _inputs(cfg, fgold):
+    import hashlib
+    rb, off, t = synthetic.formation_config(cfg)
+    h = hashlib.sha256()
+    for a in (rb, off, t):
+        h.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    assert h.hexdigest() == str(fgold[f"cfg{cfg}_sha256"]), "synthetic.formation_config drifted from the fixture"
+    return rb, off, t
+
+
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_oracle_reproduces_formation_fixture(cfg, fgold):
+    rb, off, t = _inputs(cfg, fgold)
+    G, m, _ = rb.shape
+    assert G * off.shape[0] == 4096 and m - 1 == synthetic.FORMATION_SEGMENTS[cfg]
+    wp = synthetic.formation_waypoints(O.formation_transform(rb.reshape(G * m, 7), off), G)
+    coef, dur, info, _ = c_oracle.solve_batch(wp, t, faithful=True, n_threads=0)
+    assert not info.any()
+    idx = fgold[f"cfg{cfg}_ref_idx"]
+    assert norm_rel(coef[idx], fgold[f"cfg{cfg}_ref_coef"]) <= TIGHT     # the reference's own numbers
+    S = synthetic.formation_sample_count(t)
+    pos = c_oracle.sample_positions(coef, dur, synthetic.SAMPLE_DT, S)
+    np.testing.assert_array_equal(pos[:3], O.sample_positions(coef[:3], dur[:3], synthetic.SAMPLE_DT, S))
+    md, partner, hit = c_oracle.formation_collide(pos, synthetic.DRONE_RADIUS)
+    np.testing.assert_array_equal(md, fgold[f"cfg{cfg}_pair_min_dist"])
+    np.testing.assert_array_equal(np.nonzero(hit)[0], fgold[f"cfg{cfg}_pair_hit_idx"])
+    np.testing.assert_array_equal(partner[hit], fgold[f"cfg{cfg}_pair_partner"])
+    assert 0 < hit.sum() < 0.1 * hit.size          # sparse, not empty
+    assert not (partner[hit] // 8 == np.nonzero(hit)[0] // 8).any()      # never a team mate
+    if cfg == 3:
+        mmd, mhit = c_oracle.mesh_sweep(pos, _scene(), synthetic.DRONE_RADIUS)
+        np.testing.assert_array_equal(mmd, fgold["cfg3_mesh_min_dist"])
+        np.testing.assert_array_equal(np.nonzero(mhit)[0], fgold["cfg3_mesh_hit_idx"])
+        assert 0 < mhit.sum() < 0.1 * mhit.size
+
+
+def test_c_collision_oracles_follow_the_numpy_definitions():
+    wp, t = synthetic.swarm(3, 60, 6)
+    wp[..., :3] *= 0.5
+    coef, dur, _, _ = c_oracle.solve_batch(wp, t)
+    pos = c_oracle.sample_positions(coef, dur, 0.1, 40)
+    np.testing.assert_array_equal(pos, O.sample_positions(coef, dur, 0.1, 40))
+    pos[7] = np.nan                  # a failed drone: +inf / -1 / no hit, invisible to the others (msnap.h)
+    a, b = O.formation_collide(pos, 0.2), c_oracle.formation_collide(pos, 0.2)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert np.isinf(a[0][7]) and a[1][7] == -1 and not a[2][7] and not (a[1] == 7).any()
+    tris = _scene()
+    a, b = O.mesh_sweep(pos[:5], tris, 0.3), c_oracle.mesh_sweep(pos[:5], tris, 0.3)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [2, 3])
+def test_full_size_formation_pipeline_matches_fixture(cfg, fgold, ctx7):
+    rb, off, t = _inputs(cfg, fgold)
+    G, m, _ = rb.shape
+    K = off.shape[0]
+    N = G * K
+    # a8 on the GPU, against the oracle's restatement
+    poses = ctx7.formation_transform(rb.reshape(G * m, 7), off)
+    np.testing.assert_allclose(poses, O.formation_transform(rb.reshape(G * m, 7), off), rtol=0, atol=1e-12)
+    wp = synthetic.formation_waypoints(poses, G)
+    # the solve: per-drone-grid kernel and the shared-grid MFMA GEMM
+    coef, dur, status = ctx7.solve_batch(wp, t)
+    assert (status == 0).all()
+    ctx7.prepare_grid(t)
+    gcoef, gdur, gstatus = ctx7.solve_grid(wp)
+    assert (gstatus == 0).all()
+    idx = fgold[f"cfg{cfg}_ref_idx"]
+    assert norm_rel(coef[idx], fgold[f"cfg{cfg}_ref_coef"]) <= TIGHT
+    assert norm_rel(gcoef[idx], fgold[f"cfg{cfg}_ref_coef"]) <= TIGHT
+    assert norm_rel(gcoef, coef) <= 1e-10
+    # sample -> pairwise pass
+    S = synthetic.formation_sample_count(t)
+    pos = ctx7.sample(coef, dur, synthetic.SAMPLE_DT, S, 3)
+    md, partner, hit = ctx7.formation_collide(pos, pos, synthetic.DRONE_RADIUS)
+    np.testing.assert_array_equal(np.nonzero(hit)[0], fgold[f"cfg{cfg}_pair_hit_idx"])
+    np.testing.assert_array_equal(partner[hit], fgold[f"cfg{cfg}_pair_partner"])
+    np.testing.assert_allclose(md, fgold[f"cfg{cfg}_pair_min_dist"], rtol=0, atol=1e-9)
+    # sharded as on 8 GPUs: rows of one rank against all columns
+    for r in (0, 5):
+        lo, hi = r * N // 8, (r + 1) * N // 8
+        smd, sp, sh = ctx7.formation_collide(pos[lo:hi], pos, synthetic.DRONE_RADIUS, row_offset=lo)
+        np.testing.assert_array_equal(smd, md[lo:hi])
+        np.testing.assert_array_equal(sp, partner[lo:hi])
+        np.testing.assert_array_equal(sh, hit[lo:hi])
+    if cfg == 3:
+        mmd, mhit = ctx7.mesh_sweep(pos, _scene(), synthetic.DRONE_RADIUS)
+        np.testing.assert_array_equal(np.nonzero(mhit)[0], fgold["cfg3_mesh_hit_idx"])
+        np.testing.assert_allclose(mmd, fgold["cfg3_mesh_min_dist"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_collision_passes_with_failed_and_missing_drones(ctx7):
+    """msnap.h contract: n_cols == 0 -> (+inf, -1, 0); NaN samples never win a minimum; the Python
+    pipeline refuses a shard whose solve reported failures."""
+    from drone_path_planning_python_amd import swarm as sw
+    wp, t = synthetic.swarm(3, 70, 6)
+    wp[..., :3] *= 0.5
+    wp[9, 2, 0] = np.nan
+    coef, dur, status = ctx7.solve_batch(wp, t)
+    assert status[9] == 3
+    pos = ctx7.sample(coef, dur, 0.1, 40, 3)
+    assert np.isnan(pos[9]).all()
+    md, partner, hit = ctx7.formation_collide(pos, pos, 0.2)
+    rmd, rpartner, rhit = O.formation_collide(pos, 0.2)
+    np.testing.assert_array_equal(md, rmd)
+    np.testing.assert_array_equal(partner, rpartner)
+    np.testing.assert_array_equal(hit, rhit)
+    assert np.isinf(md[9]) and partner[9] == -1 and not hit[9] and not (partner == 9).any()
+    mmd, mhit = ctx7.mesh_sweep(pos[8:11], _scene(), 0.3)
+    assert np.isinf(mmd[1]) and not mhit[1]
+    md0, p0, h0 = ctx7.formation_collide(pos[:5], pos[:0], 0.2)
+    assert np.isinf(md0).all() and (p0 == -1).all() and not h0.any()
+
+    class Comp:   # formation_pass must refuse before touching the device
+        def sample(self, *a):
+            raise AssertionError("sampled a shard with failed drones")
+    with pytest.raises(ValueError):
+        sw.formation_pass(Comp(), coef, dur, 70, 1, 0, 0.1, 40, 0.2, status_local=status)
