@@ -347,143 +347,320 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 }
 
 // ------------------------------------------------------------------------------------
-// Formation pass: for every owned drone i the minimum over all other drones j and
-// all common samples s of |p_i(s) - p_j(s)|.  One lane per row drone; the column
-// drone is wave-uniform, so its samples come through the scalar cache.  The
-// column range is sliced over blockIdx.x; a second tiny kernel merges slices.
-// Semantics are this repo's: no reference implementation exists.
+// Formation pass: for every owned drone i the minimum over all other drones j and all common
+// samples s of |p_i(s) - p_j(s)|.  Semantics are this repo's: no reference
+// implementation exists.
+//
+// Arithmetic.  One lane per row drone (row blocks of 64); the column drone is wave-uniform, its
+// samples arrive through scalar loads and are SGPR operands of the 9 operations per pair and
+// sample (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the NumPy oracle, which
+// decides ties between equidistant formation neighbours -- and the minimum).  The running minima
+// of a block of 16 columns stay in registers over all samples.  A scalar load has only an
+// all-or-nothing wait, so a wave has ONE column fetch (6 samples, 54 operations) in flight while
+// it computes the previous one; the other waves of the SIMD (5 fit) cover the rest of the latency.
+//
+// Work.  Columns that are also rows of this call (a single GPU: all of them; a shard: its own
+// 1/G) are evaluated ONCE per unordered pair: row block I meets the own-range columns from its
+// own first column on -- one-sidedly inside its diagonal block, two-sidedly behind it: d2 is
+// bitwise symmetric, so after such a block the per-column minima over the 64 rows (through a
+// per-wave LDS image) are stored as partial results of the COLUMN drones.  The (row block,
+// column) units of the whole launch form one line -- row block after row block, the columns each
+// still has to meet -- and every wave takes an equal contiguous share of it: the waves finish
+// together, no SIMD idles while another still has tiles queued (a triangular grid of whole tiles
+// leaves 2.03 tiles per wave: a third of the chip waits for the rest).  A merge kernel takes the
+// minimum over a drone's row-side shares and column-side row blocks (lowest partner index wins
+// ties on both sides).
 // ------------------------------------------------------------------------------------
-constexpr int kSampleChunk = 6;
-constexpr int kColBlock = 32;     // column drones whose running minima a lane keeps in registers
+constexpr int kRowBlock = kWave;
+constexpr int kColBlock = 16;     // column drones whose running minima a lane keeps in registers
+constexpr int kSampleChunk = 6;   // samples per scalar fetch
 
-__global__ void __launch_bounds__(kWave)
-collide_partial_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int row_offset,
-                       int Cn, int S, int cols_per_slice, double *__restrict__ part_d2,
-                       int32_t *__restrict__ part_j) {
+struct CollideGeom {
+  int R, ro, Cn, S;         // rows, global index of row 0, columns, samples
+  int os, oe;               // own range: the columns [os, oe) that are this call's rows (os == oe: none)
+  int sym;                  // own-range pairs evaluated once
+  int n_rb;                 // row blocks
+  int upw;                  // (row block, column) units per wave
+  long long total;          // units of the launch
+};
+
+// units of the row blocks before I: without the own-range shortcut every row block meets all Cn columns;
+// with it row block I skips the own-range columns before its own first one
+__device__ __host__ __forceinline__ long long collide_ustart(const CollideGeom &g, int I) {
+  return g.sym ? (long long)I * g.Cn - (long long)kRowBlock * I * (I - 1) / 2 : (long long)I * g.Cn;
+}
+
+// 6 samples of a column drone = 18 contiguous doubles in scalar registers.  The loads are issued by
+// hand: next to LDS fences the compiler can no longer prove that the position arrays are not written
+// and would fall back to vector loads of a uniform address.  SMEM returns out of order, so the only
+// wait is lgkmcnt(0); it carries the registers as operands so that no use is scheduled above it.
+typedef unsigned int u32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+struct ColChunk {
+  u32x16 a, b;
+  u32x4s c;
+  __device__ __forceinline__ void fetch(const double *p) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x80"
+                 : "=&s"(a), "=&s"(b), "=&s"(c)
+                 : "s"(p));
+  }
+  // `after` (a value the preceding arithmetic produces) pins the wait behind that arithmetic: without
+  // it the compiler may sink the other register set's VALU work below this wait and lose the overlap
+  __device__ __forceinline__ void wait(double &after) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+v"(after));
+  }
+  // i is a compile-time constant after unrolling.  Every element has exactly ONE VALU user: a scalar
+  // value with two users is first copied into vector registers (which is why a lane owns one row, not two)
+  __device__ __forceinline__ double get(int i) const {
+    return i < 8 ? __hiloint2double((int)a[2 * i + 1], (int)a[2 * i])
+                 : i < 16 ? __hiloint2double((int)b[2 * (i - 8) + 1], (int)b[2 * (i - 8)])
+                          : __hiloint2double((int)c[2 * (i - 16) + 1], (int)c[2 * (i - 16)]);
+  }
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  const int lo = __shfl_xor(__double2loint(v), mask);
+  const int hi = __shfl_xor(__double2hiint(v), mask);
+  return __hiloint2double(hi, lo);
+}
+
+// One block of NC (a multiple of 4, <= kColBlock) consecutive columns [cj, cj + ncols) against the
+// wave's 64 rows: straight-line code over the columns -- with a branch inside the column loop the
+// scalar register sets cross basic blocks and the compiler copies every fetched value into vector
+// registers (36 extra VALU moves per fetch) -- so a short block takes the next instance up and
+// re-reads its last column instead of branching.
+template <int NC>
+__device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ pr0,
+                                              const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
+                                              bool live0, int grow0, int I, int lane, double *sFold, double &best0,
+                                              int &bestj0, double *__restrict__ cpart_d2,
+                                              int32_t *__restrict__ cpart_i) {
 #pragma clang fp contract(off)
-  const int lane = threadIdx.x;
-  // Workgroup ids advance along the column slices first: consecutive ids land on different XCDs, so an
-  // XCD keeps meeting the same few slices and their column data stays in its L2 / scalar caches.
-  const int rb = blockIdx.y, sl = blockIdx.x;
-  const int r_raw = rb * kWave + lane;
-  const bool live = r_raw < R;
-  const int r = live ? r_raw : R - 1;
-  const int grow = row_offset + r;
-  const int c0 = sl * cols_per_slice;
-  int c1 = c0 + cols_per_slice;
-  if (c1 > Cn) c1 = Cn;
-  double best = INFINITY;
-  int bestj = -1;
-  const double *pr = prow + (size_t)r * S * 3;
-  if (S >= kSampleChunk) {
-    // Columns in blocks of kColBlock: a lane keeps the block's running minima in registers across
-    // all sample chunks, so the inner loop is nothing but the 9 operations per pair and sample
-    // (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the NumPy oracle -- and the
-    // minimum); self-exclusion and the partner bookkeeping happen once per column.
-    for (int jb = c0; jb < c1; jb += kColBlock) {
-      double acc[kColBlock];
+  constexpr int CH = kSampleChunk;
+  const int S = g.S;
+  const int stride = S * 3;
+  double acc0[NC];
 #pragma unroll
-      for (int jj = 0; jj < kColBlock; ++jj) acc[jj] = INFINITY;
-      for (int sc = 0; sc < S; sc += kSampleChunk) {
-        // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
-        // seeing a sample twice), so every chunk takes the wide scalar loads
-        const int s0 = (S - sc < kSampleChunk) ? S - kSampleChunk : sc;
-        double rx[kSampleChunk], ry[kSampleChunk], rz[kSampleChunk];
+  for (int jj = 0; jj < NC; ++jj) acc0[jj] = INFINITY;
+  for (int sc = 0; sc < S; sc += CH) {
+    // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
+    // seeing a sample twice), so every chunk takes the wide scalar loads
+    const int s0 = (S - sc < CH) ? S - CH : sc;
+    double ax[CH], ay[CH], az[CH];
 #pragma unroll
-        for (int q = 0; q < kSampleChunk; ++q) {
-          rx[q] = pr[(size_t)(s0 + q) * 3 + 0];
-          ry[q] = pr[(size_t)(s0 + q) * 3 + 1];
-          rz[q] = pr[(size_t)(s0 + q) * 3 + 2];
-        }
-        // the column drone's chunk is 18 contiguous doubles at a wave-uniform address -> wide scalar
-        // loads.  Scalar loads only have an all-or-nothing wait, so two register sets alternate: the
-        // loads of column j+1 are issued right after the wait for column j and fly during its
-        // 6 x 9 VALU operations.
-        auto fetch = [&](int j, double (&cb)[3 * kSampleChunk]) {
-          const int jc = j < c1 ? j : c1 - 1;
-          const double *pc = pcol + ((size_t)jc * S + s0) * 3;
-#pragma unroll
-          for (int q = 0; q < 3 * kSampleChunk; ++q) cb[q] = pc[q];
-        };
-        auto consume = [&](double &m, const double (&cb)[3 * kSampleChunk]) {
-#pragma unroll
-          for (int q = 0; q < kSampleChunk; ++q) {
-            const double dx = cb[3 * q + 0] - rx[q];
-            const double dy = cb[3 * q + 1] - ry[q];
-            const double dz = cb[3 * q + 2] - rz[q];
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            m = __builtin_fmin(d2, m);
-          }
-        };
-        double ca[3 * kSampleChunk], cb2[3 * kSampleChunk];
-        fetch(jb, ca);
-#pragma unroll
-        for (int jj = 0; jj < kColBlock; jj += 2) {
-          fetch(jb + jj + 1, cb2);
-          consume(acc[jj], ca);
-          if (jj + 2 < kColBlock) fetch(jb + jj + 2, ca);
-          consume(acc[jj + 1], cb2);
-        }
-      }
-#pragma unroll
-      for (int jj = 0; jj < kColBlock; ++jj) {
-        const int j = jb + jj;
-        const double m = (j == grow || j >= c1) ? INFINITY : acc[jj];
-        if (m < best) {     // columns ascend: the lowest index wins a tie
-          best = m;
-          bestj = j;
-        }
-      }
+    for (int q = 0; q < CH; ++q) {
+      ax[q] = pr0[(size_t)(s0 + q) * 3 + 0];
+      ay[q] = pr0[(size_t)(s0 + q) * 3 + 1];
+      az[q] = pr0[(size_t)(s0 + q) * 3 + 2];
     }
-  } else {
-    for (int j = c0; j < c1; ++j) {
-      const double *pc = pcol + (size_t)j * S * 3;
-      double m = INFINITY;
-      for (int sq = 0; sq < S; ++sq) {
-        const double dx = pc[(size_t)sq * 3 + 0] - pr[(size_t)sq * 3 + 0];
-        const double dy = pc[(size_t)sq * 3 + 1] - pr[(size_t)sq * 3 + 1];
-        const double dz = pc[(size_t)sq * 3 + 2] - pr[(size_t)sq * 3 + 2];
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        m = (d2 < m) ? d2 : m;
+    // one running pointer walks the block's columns; `nvalid` is made opaque per chunk so that the
+    // per-column strides are not hoisted out of the sample loop into spilled scalar registers
+    int nvalid = ncols;
+    asm volatile("" : "+s"(nvalid));
+    const double *pc = pcol + ((size_t)cj * S + s0) * 3;
+    auto consume = [&](double &m0, const ColChunk &k) {
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const double dx0 = k.get(3 * q + 0) - ax[q], dy0 = k.get(3 * q + 1) - ay[q], dz0 = k.get(3 * q + 2) - az[q];
+        m0 = __builtin_fmin(dx0 * dx0 + dy0 * dy0 + dz0 * dz0, m0);
       }
-      if (j == grow) m = INFINITY;
-      if (m < best) {
-        best = m;
-        bestj = j;
-      }
+    };
+    // two register sets alternate: the loads of column j+1 are issued right after the wait for
+    // column j and fly during its 6 x 9 VALU operations
+    ColChunk ca, cb2;
+    ca.fetch(pc);
+#pragma unroll
+    for (int jj = 0; jj < NC; jj += 2) {
+      pc += (jj + 1 < nvalid) ? stride : 0;
+      ca.wait(acc0[jj > 0 ? jj - 1 : 0]);
+      cb2.fetch(pc);
+      consume(acc0[jj], ca);
+      pc += (jj + 2 < nvalid) ? stride : 0;
+      cb2.wait(acc0[jj]);
+      if (jj + 2 < NC) ca.fetch(pc);
+      consume(acc0[jj + 1], cb2);
     }
   }
-  if (live) {
-    part_d2[(size_t)sl * R + r] = best;
-    part_j[(size_t)sl * R + r] = (best == INFINITY) ? -1 : bestj;
+  // row side: columns ascend, so the lowest index wins a tie
+#pragma unroll
+  for (int jj = 0; jj < NC; ++jj) {
+    const int j = cj + jj;
+    acc0[jj] = (j == grow0 || jj >= ncols) ? INFINITY : acc0[jj];
+    if (acc0[jj] < best0) {
+      best0 = acc0[jj];
+      bestj0 = j;
+    }
+  }
+  if (two_sided) {
+    // column side: min over the 64 rows of every column of the block, with the lowest row, through
+    // the LDS image [column][lane]; lane = 16 * part + column then scans a quarter of its column
+    // (rows ascend: strict '<' keeps the lowest on ties) and the four parts are folded with two
+    // exchanges.  Rows past the batch end replay row R-1 and must not win.
+#pragma unroll
+    for (int c = 0; c < NC; ++c) sFold[c * kWave + lane] = live0 ? acc0[c] : INFINITY;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    const int c = lane & (kColBlock - 1), part = lane >> 4;
+    double cm = INFINITY;
+    int ci = 0;
+    if (c < NC) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double v = sFold[c * kWave + part * 16 + k];
+        if (v < cm) {
+          cm = v;
+          ci = part * 16 + k;
+        }
+      }
+    }
+#pragma unroll
+    for (int mask = 16; mask <= 32; mask <<= 1) {
+      const double other = shfl_xor_f64(cm, mask);
+      const int oi = __shfl_xor(ci, mask);
+      const bool take = (other < cm) | ((other == cm) & (oi < ci));
+      cm = take ? other : cm;
+      ci = take ? oi : ci;
+    }
+    if (part == 0 && c < ncols) {
+      const size_t slot = (size_t)I * g.R + (size_t)(cj + c - g.os);
+      cpart_d2[slot] = cm;
+      cpart_i[slot] = (cm == INFINITY) ? -1 : g.ro + I * kRowBlock + ci;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
-__global__ void __launch_bounds__(kWave)
-collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, int R, int nsl,
-                     double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
-                     int32_t *__restrict__ hit) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  double best = INFINITY;
-  int bj = -1;
-  constexpr int U = 8;      // slices fetched per round: the loads of a round are independent
-  for (int s0 = 0; s0 < nsl; s0 += U) {
-    double v[U];
-    int j[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int s = s0 + u < nsl ? s0 + u : nsl - 1;
-      v[u] = part_d2[(size_t)s * R + r];
-      j[u] = s0 + u < nsl ? part_j[(size_t)s * R + r] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (j[u] >= 0 && (v[u] < best || (v[u] == best && j[u] < bj))) {
-        best = v[u];
-        bj = j[u];
+__global__ void __launch_bounds__(kWave, 5)
+collide_span_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, CollideGeom g,
+                    double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                    int32_t *__restrict__ cpart_i) {
+  constexpr int CB = kColBlock;
+  __shared__ double sFold[CB * kWave];
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  long long u = (long long)w * g.upw;
+  const long long u_end = u + g.upw < g.total ? u + g.upw : g.total;
+  if (u >= u_end) return;
+  // the row block the share starts in
+  int I = 0;
+  while (I + 1 < g.n_rb && collide_ustart(g, I + 1) <= u) ++I;
+  for (; u < u_end; ++I) {
+    const long long ub = collide_ustart(g, I), un = collide_ustart(g, I + 1);
+    const int ua = (int)(u - ub);                                         // first unit inside row block I
+    const int ue = (int)((u_end < un ? u_end : un) - ub);                 // one past the last
+    u = ub + ue;
+    // unit -> column: the columns left of the own range, then from the row block's own first column on
+    const int diag0 = g.os + I * kRowBlock;                               // only meaningful with g.sym
+    const int skip = g.sym ? I * kRowBlock : 0;                           // own-range columns not met
+    const int r0raw = I * kRowBlock + lane;
+    const bool live0 = r0raw < g.R;
+    const int r0 = live0 ? r0raw : g.R - 1;
+    const int grow0 = g.ro + r0;
+    const double *pr0 = prow + (size_t)r0 * g.S * 3;
+    double best0 = INFINITY;
+    int bestj0 = -1;
+    for (int ux = ua; ux < ue;) {
+      // a block: up to CB consecutive columns that do not straddle a boundary of the line
+      const int cj = (g.sym && ux >= g.os) ? ux + skip : ux;
+      int lim = ue - ux;                                                  // columns left in the share
+      bool two_sided = false;
+      if (g.sym) {
+        if (cj < g.os) lim = lim < g.os - cj ? lim : g.os - cj;                               // left of the own range
+        else if (cj < diag0 + kRowBlock) lim = lim < diag0 + kRowBlock - cj ? lim : diag0 + kRowBlock - cj;   // diagonal block
+        else if (cj < g.oe) {                                                                // behind it, still own
+          lim = lim < g.oe - cj ? lim : g.oe - cj;
+          two_sided = true;
+        }
+      }
+      const int ncols = lim < CB ? lim : CB;
+      ux += ncols;
+      switch ((ncols + 3) >> 2) {
+        case 1: collide_block<4>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
+        case 2: collide_block<8>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
+        case 3: collide_block<12>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
+        default: collide_block<16>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
       }
     }
+    // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
+    // row block) and the entries of row block I are the contiguous ids of the waves that meet it
+    const size_t id = (size_t)w + I;
+    part_d2[id * kRowBlock + lane] = best0;
+    part_j[id * kRowBlock + lane] = (best0 == INFINITY) ? -1 : bestj0;
+  }
+}
+
+// paths shorter than one sample chunk: plain loops, one-sided
+__global__ void __launch_bounds__(kWave)
+collide_short_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int ro, int Cn, int S,
+                     double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
+                     int32_t *__restrict__ hit) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * kWave + threadIdx.x;
+  if (r >= R) return;
+  const int grow = ro + r;
+  const double *pr = prow + (size_t)r * S * 3;
+  double best = INFINITY;
+  int bestj = -1;
+  for (int j = 0; j < Cn; ++j) {
+    const double *pc = pcol + (size_t)j * S * 3;
+    double m = INFINITY;
+    for (int sq = 0; sq < S; ++sq) {
+      const double dx = pc[(size_t)sq * 3 + 0] - pr[(size_t)sq * 3 + 0];
+      const double dy = pc[(size_t)sq * 3 + 1] - pr[(size_t)sq * 3 + 1];
+      const double dz = pc[(size_t)sq * 3 + 2] - pr[(size_t)sq * 3 + 2];
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      m = __builtin_fmin(d2, m);
+    }
+    if (j == grow) m = INFINITY;
+    if (m < best) {
+      best = m;
+      bestj = j;
+    }
+  }
+  const double dist = sqrt(best);
+  min_dist[r] = dist;
+  partner[r] = (best == INFINITY) ? -1 : bestj;
+  hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kWave)
+collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
+                     const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
+                     double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= g.R) return;
+  double best = INFINITY;
+  int bj = -1;
+  constexpr int U = 8;      // entries fetched per round: the loads of a round are independent
+  auto sweep = [&](const double *pd, const int32_t *pj, size_t pitch, int n) {
+    for (int s0 = 0; s0 < n; s0 += U) {
+      double v[U];
+      int j[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int s = s0 + q < n ? s0 + q : n - 1;
+        v[q] = pd[(size_t)s * pitch];
+        j[q] = s0 + q < n ? pj[(size_t)s * pitch] : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        if (j[q] >= 0 && (v[q] < best || (v[q] == best && j[q] < bj))) {
+          best = v[q];
+          bj = j[q];
+        }
+      }
+    }
+  };
+  if (g.total > 0) {
+    // row side: the shares that met this drone's row block
+    const int I = r / kRowBlock;
+    const long long wf = collide_ustart(g, I) / g.upw, wl = (collide_ustart(g, I + 1) - 1) / g.upw;
+    const size_t first = ((size_t)wf + I) * kRowBlock + (r - I * kRowBlock);
+    sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1));
+    // column side: the row blocks before this drone's own
+    if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I);
   }
   const double dist = sqrt(best);
   min_dist[r] = dist;
@@ -494,39 +671,69 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                              const double *pos_rows, const double *pos_cols, double radius, double *min_dist,
                              int32_t *partner, int32_t *hit) {
-  const int rowblocks = (n_rows + kWave - 1) / kWave;
-  if (rowblocks > 65535) return MSNAP_EINVAL;   // grid y dimension: n_rows <= 65535 * 64 per call (msnap.h)
+  CollideGeom g;
+  g.R = n_rows;
+  g.ro = row_offset;
+  g.Cn = n_cols;
+  g.S = n_samples;
+  g.n_rb = (n_rows + kRowBlock - 1) / kRowBlock;
   if (n_cols == 0) {
-    // nobody to collide with: the merge of zero slices writes inf / -1 / 0
-    hipLaunchKernelGGL(collide_merge_kernel, dim3(rowblocks), dim3(64), 0, ctx->stream, (const double *)nullptr,
-                       (const int32_t *)nullptr, n_rows, 0, radius, min_dist, partner, hit);
+    // nobody to collide with: the merge of nothing writes inf / -1 / 0
+    g.os = g.oe = 0;
+    g.sym = 0;
+    g.upw = 1;
+    g.total = 0;
+    hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream,
+                       (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
+                       (const int32_t *)nullptr, radius, min_dist, partner, hit);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
-  // column slices: enough (row block, slice) waves to fill the chip, each slice a whole number of
-  // kColBlock-column blocks
-  const int wpc = ctx->collide_waves_per_cu > 0 ? ctx->collide_waves_per_cu : 32;
-  int nsl = (ctx->n_cu * wpc + rowblocks - 1) / rowblocks;
-  if (nsl < 1) nsl = 1;
-  int cps = (n_cols + nsl - 1) / nsl;
-  cps = (cps + kColBlock - 1) / kColBlock * kColBlock;
-  if (cps < kColBlock) cps = kColBlock;
-  nsl = (n_cols + cps - 1) / cps;
-  if (nsl > 65535) {
-    nsl = 65535;
-    cps = ((n_cols + nsl - 1) / nsl + kColBlock - 1) / kColBlock * kColBlock;
-    nsl = (n_cols + cps - 1) / cps;
+  if (n_samples < kSampleChunk) {
+    hipLaunchKernelGGL(collide_short_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream,
+                       pos_rows, pos_cols, n_rows, row_offset, n_cols, n_samples, radius, min_dist, partner, hit);
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
   }
-  const size_t wbytes = (size_t)nsl * n_rows * (sizeof(double) + sizeof(int32_t));
-  int rc = ensure(ctx, ctx->stage[7], wbytes);
+  // the rows are the columns [row_offset, row_offset + n_rows) when that range exists: pairs inside it
+  // are evaluated once (unless the column-side partial buffer would be unreasonable)
+  const bool rows_in_cols = (long long)row_offset + n_rows <= n_cols;
+  g.os = rows_in_cols ? row_offset : n_cols;
+  g.oe = rows_in_cols ? row_offset + n_rows : n_cols;
+  const size_t cpart_entries = (size_t)g.n_rb * n_rows;
+  g.sym = (rows_in_cols && n_rows > kRowBlock && cpart_entries * 12 <= ((size_t)256 << 20)) ? 1 : 0;
+  g.upw = 1;
+  g.total = collide_ustart(g, g.n_rb);
+  // Equal contiguous shares of the line, one 16-column block each.  Many small shares beat one share
+  // per resident wave: the dispatcher hands the next share to whichever SIMD frees a slot, which evens
+  // out the speed differences between SIMDs (4096 x 91: 384 us with 20 shares per CU, 305 us with 32;
+  // 8192 x 96: 1.46 -> 1.06 ms); shares of 4 or 8 columns lose more to the per-block row loads than
+  // they gain (2048 x 91: 125 -> 250 us); a share that ends inside a block pays for the whole block.
+  // "collide_waves_per_cu" (tuning tools) asks for fewer, longer shares.
+  long long upw = kColBlock;
+  if (ctx->collide_waves_per_cu > 0) {
+    upw = g.total / ((long long)ctx->n_cu * ctx->collide_waves_per_cu) / kColBlock * kColBlock;
+    if (upw < kColBlock) upw = kColBlock;
+  }
+  long long waves;
+  // the row-side partial buffer holds one 64-row entry per (wave, row block) pair: bound it
+  while (((g.total + upw - 1) / upw + g.n_rb) * kRowBlock * 12 > ((long long)512 << 20)) upw *= 2;
+  g.upw = (int)upw;
+  waves = (g.total + upw - 1) / upw;
+  if (upw > 0x3fffffff || waves > 0x7fffffff) return MSNAP_EINVAL;
+  const size_t part_entries = ((size_t)waves + g.n_rb) * kRowBlock;
+  const size_t centries = g.sym ? cpart_entries : 0;
+  int rc = ensure(ctx, ctx->stage[7], (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
   double *pd = (double *)ctx->stage[7].p;
-  int32_t *pj = (int32_t *)(pd + (size_t)nsl * n_rows);
-  hipLaunchKernelGGL(collide_partial_kernel, dim3(nsl, rowblocks), dim3(kWave), 0, ctx->stream, pos_rows,
-                     pos_cols, n_rows, row_offset, n_cols, n_samples, cps, pd, pj);
+  double *cd = pd + part_entries;
+  int32_t *pj = (int32_t *)(cd + centries);
+  int32_t *ci = pj + part_entries;
+  hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream, pos_rows, pos_cols, g,
+                     pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ctx->stream, pd, pj,
-                     n_rows, nsl, radius, min_dist, partner, hit);
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream, pd, pj, g,
+                     cd, ci, radius, min_dist, partner, hit);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

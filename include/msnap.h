@@ -83,7 +83,7 @@ int msnap_host_free(void *ptr);
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
- *   "collide_waves_per_cu" (row block, column slice) waves per CU of the pairwise pass (0 = 32)
+ *   "collide_waves_per_cu" persistent waves per CU of the pairwise pass (0 = 16)
  *   "pipe_chunk_mb"        output megabytes per chunk of the chunked host-pointer solves
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
  * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_COLLIDE_WAVES_PER_CU and
@@ -190,7 +190,9 @@ int msnap_snap_cost_device(msnap_ctx *ctx, int n_drones, int n_seg, const double
  *   min_dist [n_rows]  min over other drones j != global row and samples of |p_i-p_j|
  *   partner  [n_rows]  lowest global j attaining it (-1 if none)
  *   hit      [n_rows]  min_dist < 2*radius
- * n_cols == 0 gives (+inf, -1, 0).  n_rows <= 65535 * 64 per call.
+ * pos_rows must be the rows [row_offset, row_offset + n_rows) of pos_cols (the same samples):
+ * pairs inside that range are evaluated once and credited to both drones.
+ * n_cols == 0 gives (+inf, -1, 0).
  * Non-finite samples never win a minimum (IEEE minNum): a drone whose samples are NaN -- the
  * output of a solve with status != 0 -- reports (+inf, -1, 0) and is invisible to the other
  * drones.  Check status[] of the solve before trusting a "no hit" (the Python pipeline,

@@ -86,6 +86,43 @@ def test_formation_collide_against_oracle(ctx7):
         np.testing.assert_array_equal(hit, rhit[lo:hi])
 
 
+@pytest.mark.parametrize("n,s,ro,r", [(70, 5, 0, 70), (200, 9, 0, 200), (333, 23, 0, 333), (333, 23, 100, 97),
+                                      (333, 23, 0, 64), (333, 23, 269, 64), (500, 4, 130, 370), (97, 3, 0, 97),
+                                      (1000, 13, 0, 1000), (1000, 13, 640, 200), (129, 40, 0, 129)])
+def test_formation_collide_tiles(ctx7, n, s, ro, r):
+    """The tile kernel: pairs inside the rows' own column range are evaluated once and credited to
+    both drones (column-side minima through the register butterfly), everything else one-sidedly.
+    Row counts around the 64-row / 32-column block edges, shards at unaligned offsets, sample counts
+    around the 4-sample chunk, with exact ties between equidistant neighbours (lattice positions):
+    distances, partners (lowest index wins) and hits must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(1000 * n + s)
+    pos = rng.uniform(-3.0, 3.0, size=(n, s, 3))
+    # a lattice part: many exactly equal distances, so partner choice is decided by the index rule
+    k = n // 3
+    pos[:k] = np.round(pos[:k] * 2.0) / 2.0
+    pos[5] = pos[4] + np.array([0.25, 0.0, 0.0])           # a close pair across the whole path
+    rmd, rpartner, rhit = O.formation_collide(pos, 0.3)
+    md, partner, hit = ctx7.formation_collide(pos[ro:ro + r], pos, 0.3, row_offset=ro)
+    np.testing.assert_array_equal(md, rmd[ro:ro + r])
+    np.testing.assert_array_equal(partner, rpartner[ro:ro + r])
+    np.testing.assert_array_equal(hit, rhit[ro:ro + r])
+
+
+def test_formation_collide_rows_not_among_columns(ctx7):
+    """rows beyond the columns (row_offset + n_rows > n_cols): one-sided everywhere, no self to exclude."""
+    rng = np.random.default_rng(77)
+    pos = rng.uniform(-2.0, 2.0, size=(150, 11, 3))
+    md, partner, hit = ctx7.formation_collide(pos[100:150], pos[:120], 0.3, row_offset=100)
+    ref = O.formation_collide(pos[:120], 0.3)
+    np.testing.assert_array_equal(md[:20], ref[0][100:120])     # rows 100..119 are columns too
+    np.testing.assert_array_equal(partner[:20], ref[1][100:120])
+    for q in range(20, 50):                                    # rows 120..149 meet every column
+        d = pos[:120] - pos[100 + q][None]
+        sq = d * d
+        d2 = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]).min(axis=1)
+        assert md[q] == np.sqrt(d2.min()) and partner[q] == int(np.argmin(d2))
+
+
 def test_mesh_sweep_against_oracle(ctx7, tmp_path):
     from drone_path_planning_python_amd import stl
     wall = stl.box_mesh((-2, 3.9, 0), (2, 4.1, 1.6))        # env-scene-ltu-experiment.stl's box

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Times the pairwise formation pass (K5) on the configs[2] shape for the tile shapes and wave counts
+the context options expose; prints one line per setting.  GPU box only."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from drone_path_planning_python_amd import Context  # noqa: E402
+
+VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 91
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    pos = torch.from_numpy(rng.uniform(-50, 50, size=(N, S, 3))).to(dev)
+    md = torch.empty((N,), dtype=torch.float64, device=dev)
+    partner = torch.empty((N,), dtype=torch.int32, device=dev)
+    hit = torch.empty((N,), dtype=torch.int32, device=dev)
+    ctx = Context(0, 7, 16)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ref = None
+    for variant in (0,):
+        for wpc in (0, 16, 64):
+            ctx.set_option("collide_waves_per_cu", wpc)
+            for _ in range(3):
+                ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / reps * 1e3
+            out = (md.cpu().numpy().copy(), partner.cpu().numpy().copy())
+            if ref is None:
+                ref = out
+            same = np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+            alg = N * (N - 1) / 2 * S * 9
+            print(json.dumps({"N": N, "S": S, "waves_per_cu": wpc, "us": round(us, 1),
+                              "frac_of_f64_issue_peak_on_unordered_pairs": round(alg / (us * 1e-6) / VALU_F64_OPS, 3),
+                              "same_result": bool(same)}), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
