@@ -60,9 +60,9 @@ HBM_COPY_GBS = 6290.0
 VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
 PAIR_OPS = 9                   # 3 differences, 3 products, 2 sums, 1 minimum per pair and sample
-# instructions per point-triangle test on the face-region path of mesh_sweep_kernel (counted in the
-# ISA); vertex / edge regions exit earlier, so this prices every test at the longest path
-MESH_TEST_OPS = 104
+# vector instructions of one point-triangle test in mesh_sweep_kernel's code object, all closest-point
+# regions together (a wave whose samples fall into several regions walks all of them)
+MESH_TEST_OPS = 290
 
 
 def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
@@ -88,6 +88,16 @@ def pmc_traffic(n_drones: int, n_seg: int, order: int):
         return ent.get("hbm_bytes_per_launch"), ent.get("kernel")
     except Exception:
         return None, None
+
+
+def pmc_counter(kernel: str, counter: str):
+    """Mean per launch of a PMC counter of one kernel on the bench's own workload, from the committed
+    passes (profiles/pmc_counters.json, tools/make_profiles.sh); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
+            return json.load(f).get(kernel, {}).get(counter)
+    except Exception:
+        return None
 
 
 def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
@@ -368,31 +378,34 @@ def run_formation_config(cfg, env, reps, warm):
         tris = torch.from_numpy(np.concatenate([stl.load_stl(os.path.join(gd, "env-scene-hole.stl")),
                                                 stl.load_stl(os.path.join(gd, "env-scene-ltu-experiment.stl"))])
                                 ).to(device)
-    stage_names = ["solve", "sample", "allgather", "pairwise"] + (["mesh"] if cfg == 3 else [])
+    stage_names = ["solve", "sample"] + (["allgather"] if world > 1 else []) + ["pairwise"] + (["mesh"] if cfg == 3 else [])
     nst = len(stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
 
     def one(rec):
-        if rec:
-            rec[0].record()
+        k = 0
+
+        def mark():
+            nonlocal k
+            if rec:
+                rec[k].record()
+            k += 1
+        mark()
         coef, dur, status = comp.solve(twp, tt)
-        if rec:
-            rec[1].record()
+        mark()
         pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
-        if rec:
-            rec[2].record()
-        pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch) if world > 1 else pos
-        if rec:
-            rec[3].record()
+        mark()
+        pos_all = pos
+        if world > 1:
+            pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch)
+            mark()
         md, partner, hit = comp.collide(pos, lo, pos_all, synthetic.DRONE_RADIUS)
-        if rec:
-            rec[4].record()
+        mark()
         mh = None
         if tris is not None:
             _, mh = comp.mesh(pos, tris, synthetic.DRONE_RADIUS)
-            if rec:
-                rec[5].record()
-        return status, hit, mh, md
+            mark()
+        return status, hit, mh, md, pos
 
     for _ in range(warm):
         one(None)
@@ -402,7 +415,7 @@ def run_formation_config(cfg, env, reps, warm):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for r in range(reps):
-        status, hit, mh, md = one(ev[r])
+        status, hit, mh, md, pos_keep = one(ev[r])
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if use_pg:
@@ -432,7 +445,8 @@ def run_formation_config(cfg, env, reps, warm):
     fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz"))
     n_max = max(swarm.shard_sizes(N, world))
     pair_alg = N * (N - 1) / 2 * S * PAIR_OPS                 # every unordered pair once
-    pair_exec = n_max * N * S * PAIR_OPS                       # what the largest shard evaluates
+    # what the largest shard evaluates: its rows against the other shards' columns, its own block once per pair
+    pair_exec = (n_max * (N - n_max) + n_max * (n_max + 63) / 2) * S * PAIR_OPS
     rep = {
         "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
@@ -450,25 +464,40 @@ def run_formation_config(cfg, env, reps, warm):
                                        "note": "same shard through K2, outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "allgather": {"bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24 if world > 1 else 0,
-                          "frac": ((N - n_max) * S * 24 / (st["allgather"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS))
-                          if world > 1 and st["allgather"] > 0 else None},
-            "pairwise": {"kernel": "msnap::collide_partial_kernel + collide_merge_kernel", "bound": "valu_f64",
+            "pairwise": {"kernel": "msnap::collide_span_kernel + collide_merge_kernel", "bound": "valu_f64",
                          "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "note": "frac counts each unordered pair once (N(N-1)/2 x S x 9 operations, SURVEY.md 8d), "
                                  "per GPU; frac_executed counts the pair-samples the kernel evaluates"},
         },
     }
+    if world > 1:
+        rep["stages"]["allgather"] = {
+            "collective": "all_gather_into_tensor (RCCL)" if env["coll"] is dist else "host rehearsal (gloo)",
+            "bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24,
+            "frac": (N - n_max) * S * 24 / (st["allgather"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
     if cfg == 3:
         rep["mesh_hits"] = cnt[2]
         rep["mesh_hits_fixture"] = int(fix["cfg3_mesh_hit_idx"].size)
         tests = n_max * S * int(tris.shape[0])
-        rep["stages"]["mesh"] = {"kernel": "msnap::mesh_sweep_kernel", "bound": "valu_f64",
-                                 "point_triangle_tests_per_s": tests / (st["mesh"] * 1e-6),
-                                 "frac": tests * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
-                                 "note": f"{MESH_TEST_OPS} fp64 operations per test (face-region path, every test "
-                                         "priced at the longest path; tests culled by the segment bounds count as done)"}
+        # how many of them the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
+        ctx.set_option("mesh_count_tests", 1)
+        comp.mesh(pos_keep, tris, synthetic.DRONE_RADIUS)
+        evaluated = ctx.get_option("mesh_count_tests")
+        ctx.set_option("mesh_count_tests", 0)
+        valu = pmc_counter("mesh_sweep_kernel", "SQ_INSTS_VALU") if world == 1 else None
+        rep["stages"]["mesh"] = {
+            "kernel": "msnap::mesh_sweep_kernel", "bound": "valu_f64",
+            "point_triangle_pairs": tests, "tests_evaluated": evaluated,
+            "point_triangle_pairs_per_s": tests / (st["mesh"] * 1e-6),
+            "tests_evaluated_per_s": evaluated / (st["mesh"] * 1e-6),
+            "frac": (valu * 64 / (st["mesh"] * 1e-6) / VALU_F64_OPS) if valu else None,
+            "note": "exact cull: a triangle whose bounding box is farther from the wave's stretch of path than "
+                    "the best distance so far is skipped; frac = vector instructions per launch (SQ_INSTS_VALU "
+                    "of profiles/pmc_counters.json, this workload) x 64 lanes / time / fp64 issue peak"}
+    return rep
+
+
     return rep
 
 

@@ -123,6 +123,7 @@ void msnap_destroy(msnap_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
+  if (ctx->mesh_tests) (void)hipFree(ctx->mesh_tests);
   for (msnap::DevBuf *b : {&ctx->grid_t, &ctx->grid_wp, &ctx->grid_op, &ctx->grid_dur, &ctx->grid_status, &ctx->grid_frag})
     if (b->p) (void)hipFree(b->p);
   for (auto &b : ctx->stage)
@@ -159,6 +160,17 @@ int msnap_set_option(msnap_ctx *ctx, const char *name, long value) {
     ctx->pipe_chunk_bytes = (size_t)(value > 0 ? value : 64) << 20;
     return MSNAP_OK;
   }
+  if (!strcmp(name, "mesh_count_tests")) {
+    MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+    MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (value && !ctx->mesh_tests) MSNAP_HIP(ctx, hipMalloc(&ctx->mesh_tests, 8));
+    if (ctx->mesh_tests) MSNAP_HIP(ctx, hipMemset(ctx->mesh_tests, 0, 8));
+    if (!value && ctx->mesh_tests) {
+      (void)hipFree(ctx->mesh_tests);
+      ctx->mesh_tests = nullptr;
+    }
+    return MSNAP_OK;
+  }
   int *slot = option_slot(ctx, name);
   if (!slot) return MSNAP_EINVAL;
   *slot = (int)value;
@@ -169,6 +181,16 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
   if (!ctx || !name || !value) return MSNAP_EINVAL;
   if (!strcmp(name, "pipe_chunk_mb")) {
     *value = (long)(ctx->pipe_chunk_bytes >> 20);
+    return MSNAP_OK;
+  }
+  if (!strcmp(name, "mesh_count_tests")) {   // the count since it was last set (synchronises the stream)
+    unsigned long long n = 0;
+    if (ctx->mesh_tests) {
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+          hipMemcpy(&n, ctx->mesh_tests, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return MSNAP_EHIP;
+    }
+    *value = (long)n;
     return MSNAP_OK;
   }
   const int *slot = option_slot(const_cast<msnap_ctx *>(ctx), name);

@@ -740,8 +740,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
 
 // ------------------------------------------------------------------------------------
 // Mesh sweep: min over samples and triangles of the point-triangle distance
-// (closest-point regions, Ericson 5.1.5).  One wavefront per drone, lanes stride
-// the samples; the triangle is wave-uniform (scalar loads).  Semantics are this
+// (closest-point regions, Ericson 5.1.5).  One workgroup per drone, one lane per
+// sample; the triangle is wave-uniform (scalar loads).  Semantics are this
 // repo's; the reference only has a boolean FCL mesh-mesh test in the
 // planner (src/RigidBodyPlanners/fcl_checker.py:93-100).
 // ------------------------------------------------------------------------------------
@@ -801,40 +801,110 @@ __device__ __forceinline__ double pt_tri_d2(double px, double py, double pz, con
   return ex * ex + ey * ey + ez * ez;
 }
 
-__global__ void __launch_bounds__(kWave)
+// fp64 min / max over the 64 lanes of a wave (every lane gets the result): four DPP stages inside
+// the rows of 16 (lane xor 1, xor 2, mirror of 8, mirror of 16), two exchanges across the rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_f64(double v) {
+  auto fold = [](double a, double b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
+  v = fold(v, dpp_f64<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fold(v, dpp_f64<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fold(v, dpp_f64<0x141>(v));    // row_half_mirror
+  v = fold(v, dpp_f64<0x140>(v));    // row_mirror
+  v = fold(v, __shfl_xor(v, 16));
+  v = fold(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
+__device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
+
+// the value of lane 0 as a compiler-visible wave-uniform value (after a wave reduction every lane holds
+// the same number, but only this makes the branches and triangle loads that depend on it scalar)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// squared distance between the box [lo, hi] and the bounding box of triangle t: a lower bound of every
+// point-triangle distance between them
+__device__ __forceinline__ double box_tri_lb2(const double (&lo)[3], const double (&hi)[3], const double *__restrict__ t) {
+#pragma clang fp contract(off)
+  double lb2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double tmin = fmin(t[k], fmin(t[3 + k], t[6 + k])), tmax = fmax(t[k], fmax(t[3 + k], t[6 + k]));
+    const double gap = fmax(0.0, fmax(lo[k] - tmax, tmin - hi[k]));
+    lb2 = lb2 + gap * gap;
+  }
+  return lb2;
+}
+
+// One workgroup per drone, one lane per sample (ceil(S / 64) waves, at most 16); the triangle under
+// test is wave-uniform: its vertices are scalar loads and scalar operands.
+// Exact culling per wave.  The squared distance between a triangle's bounding box and the bounding box
+// of the wave's stretch of path is a lower bound of every point-triangle distance of that pair, so a
+// triangle whose bound is not below the best distance found so far cannot lower the minimum.  Lane t
+// of the wave holds the bound of triangle t (groups of 64 triangles); the wave repeatedly takes the
+// triangle with the smallest bound, tests it against its 64 samples, and stops the group as soon as the
+// smallest remaining bound is not below the best distance: a path far from the scene tests one or
+// two triangles, a path through a wall all of the wall's.  min_dist stays the exact minimum over all
+// samples and triangles -- a skipped test could only have returned something larger.
+__global__ void __launch_bounds__(1024)
 mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__restrict__ tris, int n_tris,
-                  double radius, double *__restrict__ min_dist, int32_t *__restrict__ hit) {
+                  double radius, double *__restrict__ min_dist, int32_t *__restrict__ hit,
+                  unsigned long long *__restrict__ tests_done) {
+  __shared__ double sBest[16];
   const int d = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, nw = blockDim.x / kWave;
   double best = INFINITY;
-  // Typical paths have 64 < S < 128 samples: with one sample per lane the second pass would run
-  // half empty.  The wave is split instead: 32 samples per pass, the two half-waves take the even
-  // and the odd triangles (the triangle is then uniform per half-wave, its 9 doubles come from L1).
-  const int sl = lane & 31, half = lane >> 5;
-  for (int s = sl; s < S; s += 32) {
-    const double *p = pos + ((size_t)d * S + s) * 3;
+  unsigned long long done = 0;
+  for (int s0 = wv * kWave; s0 < S; s0 += nw * kWave) {      // one trip unless S > 1024
+    const int s = s0 + lane;
+    const double *p = pos + ((size_t)d * S + (s < S ? s : S - 1)) * 3;   // lanes past the end replay the last sample
     const double px = p[0], py = p[1], pz = p[2];
-    for (int t = half; t < n_tris; t += 2) {
-      const double v = pt_tri_d2(px, py, pz, tris + (size_t)t * 9);
-      best = (v < best) ? v : best;
+    double lo[3], hi[3];
+    lo[0] = wave_min_f64(px); lo[1] = wave_min_f64(py); lo[2] = wave_min_f64(pz);
+    hi[0] = wave_max_f64(px); hi[1] = wave_max_f64(py); hi[2] = wave_max_f64(pz);
+    double wbest = uniform_f64(wave_min_f64(best));            // wave-uniform bound: min over the lanes so far
+    for (int t0 = 0; t0 < n_tris; t0 += kWave) {
+      const int tl = t0 + lane;
+      double lb = (tl < n_tris) ? box_tri_lb2(lo, hi, tris + (size_t)(tl < n_tris ? tl : 0) * 9) : INFINITY;
+      for (;;) {
+        const double m = uniform_f64(wave_min_f64(lb));
+        if (!(m < wbest)) break;                               // also ends the group when every bound is spent (inf)
+        const unsigned long long holders = __ballot(lb == m);
+        const int sel = __builtin_ctzll(holders);              // wave-uniform: the ballot is a scalar
+        lb = (lane == sel) ? INFINITY : lb;
+        const double v = pt_tri_d2(px, py, pz, tris + (size_t)(t0 + sel) * 9);
+        best = (v < best) ? v : best;
+        wbest = uniform_f64(wave_min_f64(best));
+        done += 1;
+      }
     }
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const double other = __shfl_xor(best, o);
-    best = (other < best) ? other : best;
-  }
-  if (lane == 0) {
+  best = wave_min_f64(best);
+  if (lane == 0) sBest[wv] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < nw; ++k) best = (sBest[k] < best) ? sBest[k] : best;
     const double dist = sqrt(best);
     min_dist[d] = dist;
     hit[d] = (dist < radius) ? 1 : 0;
   }
+  if (tests_done && lane == 0) atomicAdd(tests_done, done * kWave);
 }
 
 int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
                       const double *tris, double radius, double *min_dist, int32_t *hit) {
-  hipLaunchKernelGGL(mesh_sweep_kernel, dim3(n_drones), dim3(kWave), 0, ctx->stream, pos, n_drones, n_samples,
-                     tris, n_tris, radius, min_dist, hit);
+  int waves = (n_samples + kWave - 1) / kWave;
+  if (waves > 16) waves = 16;
+  hipLaunchKernelGGL(mesh_sweep_kernel, dim3(n_drones), dim3(waves * kWave), 0, ctx->stream, pos, n_drones,
+                     n_samples, tris, n_tris, radius, min_dist, hit, (unsigned long long *)ctx->mesh_tests);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

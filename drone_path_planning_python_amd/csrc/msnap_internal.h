@@ -90,7 +90,8 @@ struct msnap_ctx {
   int twist_max_drones = 0;     // "twist_max_drones": batches up to this size take the small-batch kernel (0: default)
   int solve_grid_waves = 0;     // "solve_grid_waves": cap on solve_kernel_reg's persistent grid (0: default)
   int gemm_grid_waves = 0;      // "gemm_grid_waves": cap on the shared-grid GEMM's persistent grid (0: default)
-  int collide_waves_per_cu = 0; // "collide_waves_per_cu": persistent waves per CU of the pairwise pass (0: 16)
+  void *mesh_tests = nullptr;   // "mesh_count_tests": device counter of the point-triangle tests evaluated (not culled)
+  int collide_waves_per_cu = 0; // "collide_waves_per_cu": shares per CU of the pairwise pass (0: one column block per share)
   char hip_err[256] = {0};
 };
 

@@ -83,7 +83,10 @@ int msnap_host_free(void *ptr);
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
- *   "collide_waves_per_cu" persistent waves per CU of the pairwise pass (0 = 16)
+ *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 16-column block per share)
+ *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
+ *                          its bounding-box cull does not skip); msnap_get_option returns the count
+ *                          since the option was last set (and synchronises the stream); 0: off
  *   "pipe_chunk_mb"        output megabytes per chunk of the chunked host-pointer solves
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
  * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_COLLIDE_WAVES_PER_CU and
