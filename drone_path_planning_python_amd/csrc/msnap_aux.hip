@@ -141,52 +141,174 @@ int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const
 // running sum of durations, last piece extrapolates; Horner of :17-22 with
 // separate multiply and add, hence fp contract off for bit parity)
 // ------------------------------------------------------------------------------------
+// Generic form: one thread per (drone, sample), the reference's search loop as it stands.  Used for
+// drones whose durations are not all >= 0 (the search is then not a partition into ranges), for
+// dt == 0 and for paths whose samples do not fit the LDS image of the fast kernel.
+template <int NC>
+__device__ __forceinline__ void sample_point_generic(const double *__restrict__ coef, const double *__restrict__ dr,
+                                                     int M, double t, int a, double &x) {
+#pragma clang fp contract(off)
+  double acc = 0.0;
+  int seg = M - 1;
+  bool found = false;
+  for (int i = 0; i < M; ++i) {
+    const double Ti = dr[i];
+    if (!found && t < acc + Ti) {
+      seg = i;
+      found = true;
+    }
+    if (!found && i < M - 1) acc = acc + Ti;
+  }
+  // not found: acc == sum(dur[:-1]) and seg == M-1 (uav_trajectory.py:161-163)
+  const double tl = t - acc;
+  const double *c = coef + ((size_t)seg * 4 + a) * NC;
+  x = 0.0;
+#pragma unroll
+  for (int q = NC - 1; q >= 0; --q) x = x * tl + c[q];
+}
+
 template <int NC>
 __global__ void __launch_bounds__(256)
-sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
-              int naxes, double *__restrict__ pos) {
-#pragma clang fp contract(off)
+sample_generic_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
+                      int naxes, double *__restrict__ pos) {
   const size_t total = (size_t)N * S;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
     const int d = (int)(idx / S);
     const int s = (int)(idx - (size_t)d * S);
-    const double t = (double)s * dt;
-    const double *dr = dur + (size_t)d * M;
-    double acc = 0.0;
-    int seg = M - 1;
-    bool found = false;
-    for (int i = 0; i < M; ++i) {
-      const double Ti = dr[i];
-      if (!found && t < acc + Ti) {
-        seg = i;
-        found = true;
-      }
-      if (!found && i < M - 1) acc = acc + Ti;
-    }
-    // not found: acc == sum(dur[:-1]) and seg == M-1 (uav_trajectory.py:161-163)
-    const double tl = t - acc;
-    const double *c = coef + ((size_t)d * M + seg) * 4 * NC;
     for (int a = 0; a < naxes; ++a) {
-      double x = 0.0;
-#pragma unroll
-      for (int q = NC - 1; q >= 0; --q) x = x * tl + c[a * NC + q];
+      double x;
+      sample_point_generic<NC>(coef + (size_t)d * M * 4 * NC, dur + (size_t)d * M, M, (double)s * dt, a, x);
       pos[idx * naxes + a] = x;
     }
   }
 }
 
+// Fast form: one thread per (drone, piece, axis).  The reference's search `t < acc + T_i` over the
+// running sum acc (uav_trajectory.py:157-165) partitions the sample times into one range per piece when
+// every duration is >= 0: piece i owns the samples with b_i <= s*dt < b_{i+1}, b the running sum exactly
+// as the reference accumulates it (the last piece also owns everything from b_M on and keeps its origin
+// b_{M-1}: the extrapolation of :161-163).  The range's first sample is found from b_i / dt and then
+// corrected against fl(s*dt) >= b_i itself, so the partition is the reference's bit for bit.  The thread
+// keeps its coefficient row in registers over its samples (the (drone, sample) form re-reads a row per
+// sample and gates the coefficient address behind M dependent duration loads: 34 % of the HBM rate).
+// A workgroup owns DW whole drones; results go through an LDS image of their [S][naxes] blocks and
+// leave as 16-byte-per-lane runs (direct 8-byte stores at a 24-byte stride reach L2 as 21-byte requests).
+template <int NC>
+__global__ void __launch_bounds__(256)
+sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
+              int naxes, int DW, double *__restrict__ pos) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *sB = smem;                                    // [DW][M + 1] running sums, b_0 = 0
+  int *sGen = reinterpret_cast<int *>(sB + (size_t)DW * (M + 1));   // [DW] 1: this drone takes the generic search
+  double *sImg = reinterpret_cast<double *>(sGen + ((DW + 1) & ~1));  // [DW][S][naxes]
+  const int tid = threadIdx.x;
+  const size_t per_drone = (size_t)S * naxes;
+  for (int d0 = blockIdx.x * DW; d0 < N; d0 += gridDim.x * DW) {
+    const int nd = N - d0 < DW ? N - d0 : DW;
+    if (tid < nd) {
+      const double *dr = dur + (size_t)(d0 + tid) * M;
+      double acc = 0.0;
+      bool ranges = dt > 0.0;
+      sB[tid * (M + 1)] = 0.0;
+      for (int i = 0; i < M; ++i) {
+        const double Ti = dr[i];
+        ranges = ranges && (Ti >= 0.0);
+        acc = acc + Ti;
+        sB[tid * (M + 1) + i + 1] = acc;
+      }
+      sGen[tid] = ranges ? 0 : 1;
+    }
+    __syncthreads();
+    const int items = nd * M * naxes;
+    for (int it = tid; it < items; it += blockDim.x) {
+      const int a = it % naxes;
+      const int i = (it / naxes) % M;
+      const int dl = it / (naxes * M);
+      const double *cbase = coef + (size_t)(d0 + dl) * M * 4 * NC;
+      double *img = sImg + (size_t)dl * per_drone;
+      if (sGen[dl]) {
+        if (i == 0)       // rare: one thread per axis walks the whole path with the reference's own loop
+          for (int sq = 0; sq < S; ++sq)
+            sample_point_generic<NC>(cbase, dur + (size_t)(d0 + dl) * M, M, (double)sq * dt, a, img[(size_t)sq * naxes + a]);
+        continue;
+      }
+      const double bi = sB[dl * (M + 1) + i], bn = sB[dl * (M + 1) + i + 1];
+      // first sample with fl(s*dt) >= b: the quotient is a guess, the products decide
+      auto first_at = [&](double b) -> int {
+        const double x = b / dt;
+        int c = x >= (double)S ? S : (int)x;
+        while (c > 0 && (double)(c - 1) * dt >= b) --c;
+        while (c < S && (double)c * dt < b) ++c;
+        return c;
+      };
+      const int s_lo = (i == 0) ? 0 : first_at(bi);
+      const int s_hi = (i == M - 1) ? S : first_at(bn);
+      if (s_lo >= s_hi) continue;
+      double c[NC];
+      const double *crow = cbase + ((size_t)i * 4 + a) * NC;
+#pragma unroll
+      for (int q = 0; q < NC; q += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(crow + q);
+        c[q] = v.x;
+        c[q + 1] = v.y;
+      }
+      for (int sq = s_lo; sq < s_hi; ++sq) {
+        const double tl = (double)sq * dt - bi;
+        double x = 0.0;
+#pragma unroll
+        for (int q = NC - 1; q >= 0; --q) x = x * tl + c[q];
+        img[(size_t)sq * naxes + a] = x;
+      }
+    }
+    __syncthreads();
+    // the nd drones' blocks are contiguous in pos: 16 bytes per lane (per_drone * nd doubles; odd tail by one lane)
+    const size_t words = per_drone * nd;
+    double *out = pos + (size_t)d0 * per_drone;
+    const bool aligned = ((size_t)d0 * per_drone & 1) == 0;
+    if (aligned) {
+      for (size_t e = (size_t)tid * 2; e + 1 < words; e += (size_t)blockDim.x * 2)
+        *reinterpret_cast<double2 *>(out + e) = *reinterpret_cast<const double2 *>(sImg + e);
+      if ((words & 1) && tid == 0) out[words - 1] = sImg[words - 1];
+    } else {
+      for (size_t e = tid; e < words; e += blockDim.x) out[e] = sImg[e];
+    }
+    __syncthreads();
+  }
+}
+
 int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
                   int n_samples, int n_axes, double *pos) {
-  const size_t total = (size_t)n_drones * n_samples;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > (size_t)ctx->n_cu * 16) blocks = (size_t)ctx->n_cu * 16;
-  if (ctx->order == 7)
-    hipLaunchKernelGGL((sample_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
-                       n_drones, n_seg, n_samples, n_axes, pos);
-  else
-    hipLaunchKernelGGL((sample_kernel<10>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
-                       n_drones, n_seg, n_samples, n_axes, pos);
+  // drones per workgroup: about 256 (piece, axis) threads, within 48 KB of LDS image
+  const size_t img_per_drone = (size_t)n_samples * n_axes * sizeof(double);
+  int dw = 256 / (n_seg * n_axes);
+  if (dw < 1) dw = 1;
+  if (dw > 16) dw = 16;
+  while (dw > 1 && dw * img_per_drone > 48 * 1024) --dw;
+  const size_t lds = ((size_t)dw * (n_seg + 1)) * sizeof(double) + (((size_t)dw + 1) & ~(size_t)1) * sizeof(int) +
+                     dw * img_per_drone;
+  if (lds <= 64 * 1024) {
+    size_t blocks = ((size_t)n_drones + dw - 1) / dw;
+    if (blocks > (size_t)ctx->n_cu * 64) blocks = (size_t)ctx->n_cu * 64;
+    if (ctx->order == 7)
+      hipLaunchKernelGGL((sample_kernel<8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
+                         n_drones, n_seg, n_samples, n_axes, dw, pos);
+    else
+      hipLaunchKernelGGL((sample_kernel<10>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
+                         n_drones, n_seg, n_samples, n_axes, dw, pos);
+  } else {
+    // one drone's samples exceed the image: the (drone, sample) form
+    const size_t total = (size_t)n_drones * n_samples;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > (size_t)ctx->n_cu * 16) blocks = (size_t)ctx->n_cu * 16;
+    if (ctx->order == 7)
+      hipLaunchKernelGGL((sample_generic_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
+                         n_drones, n_seg, n_samples, n_axes, pos);
+    else
+      hipLaunchKernelGGL((sample_generic_kernel<10>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
+                         n_drones, n_seg, n_samples, n_axes, pos);
+  }
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

@@ -65,6 +65,42 @@ def test_sampler_bit_exact_incl_knots_and_past_end(ctx7, golden):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("n,m,s_extra,dt,naxes", [(1, 1, 3, 0.1, 3), (7, 3, 5, 0.07, 4), (33, 10, 0, 0.1, 3), (300, 10, 9, 0.1, 3),
+                                                  (19, 20, 2, 0.25, 3), (5, 49, 0, 0.1, 4), (3, 120, 4, 0.05, 3),
+                                                  (9, 6, 0, 0.0, 3), (4, 10, 3000, 0.01, 3), (64, 8, 1, 1.0 / 3.0, 3)])
+def test_sampler_ranges_bit_exact(ctx7, n, m, s_extra, dt, naxes):
+    """The (drone, piece, axis) sampler against the reference's search loop (C and NumPy oracles), bit for
+    bit: piece boundaries on and off the sample grid, zero-length pieces, drones with negative or NaN
+    durations (the generic search), dt = 0, paths longer than the LDS image (the generic kernel)."""
+    import c_oracle
+    rng = np.random.default_rng(100 * n + m)
+    coef = rng.normal(size=(n, m, 4, 8))
+    dur = rng.uniform(0.3, 1.7, size=(n, m))
+    dur[0, :] = np.round(dur[0, :] * 10.0) / 10.0             # knots on multiples of 0.1
+    if n > 2 and m > 2:
+        dur[1, 1] = 0.0                                        # a piece that owns no sample
+        dur[2, m // 2] = -0.4                                  # not a partition: the generic search
+    if n > 4:
+        dur[4, 0] = np.nan
+    total = float(np.nanmax(np.nansum(np.abs(dur), axis=1)))
+    S = (int(total / dt) if dt > 0 else 7) + 1 + s_extra
+    got = ctx7.sample(coef, dur, dt, S, naxes)
+    ref = c_oracle.sample_positions(coef, dur, dt, S, naxes)
+    np.testing.assert_array_equal(got, ref)
+    good = [d for d in range(n) if (dur[d] >= 0).all()][:3]    # the reference asserts on a negative local time
+    np.testing.assert_array_equal(got[good, :40], O.sample_positions(coef[good], dur[good], dt, min(S, 40), naxes=naxes))
+
+
+def test_sampler_order9_and_solved_swarm(ctx9):
+    import c_oracle
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(21, 50, 10)
+    coef, dur, status = ctx9.solve_batch(wp, t)
+    assert (status == 0).all()
+    S = int(dur.sum(axis=1).max() / 0.1) + 4
+    np.testing.assert_array_equal(ctx9.sample(coef, dur, 0.1, S, 3), c_oracle.sample_positions(coef, dur, 0.1, S, 3))
+
+
 def test_formation_collide_against_oracle(ctx7):
     rng = np.random.default_rng(4)
     for n, S in [(1, 5), (2, 3), (37, 21), (300, 9)]:
