@@ -790,7 +790,8 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   // backward sweep, when most of this tile's registers are dead.  (Requesting them right after the
   // forward sweep hides more latency on paper but measured 4 % slower at saturation)
   // `stores_after_prefetch` is the exact number of younger store instructions the wait must leave
-  // in flight; tools/check_prefetch_isa.py checks it against the code object at build time.
+  // in flight (tools/check_prefetch_isa.py counts them in the code object; the multi-tile tests of
+  // tests/test_solve_gpu.py compare a persistent wave's tiles with the same tiles solved alone).
   constexpr int kStoresPerSeg = (NC == 8 ? 4 : NC / 2);
   const int stores_after_prefetch = kStoresPerSeg * (M >= 2 ? 2 : 1);
 

@@ -410,6 +410,21 @@ def trajectory_eval(matrix: np.ndarray, t: float):
     return None
 
 
+def nav_path_poses(matrix: np.ndarray, timestep: float, offset=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """get_nav_path_msg (src/trajectory_visualising/visualization.py:39-71) as an array [n, 7] of
+    (x, y, z, qx, qy, qz, qw): one row per t in np.arange(0, duration, timestep) (:53), position =
+    Trajectory.eval(t).pos + offset (:58-60), orientation = quaternion_from_euler(0, 0, -yaw) (:62-63).
+    tf is not vendored in the reference; for roll = pitch = 0 its published 'sxyz' algorithm gives
+    (0, 0, sin(yaw/2), cos(yaw/2)) -- parity unpinned."""
+    duration = float(np.sum(matrix[:, 0]))
+    rows = []
+    for t in np.arange(0, duration, timestep):
+        pos, _, _, _, yaw = trajectory_eval(matrix, float(t))
+        h = 0.5 * (-yaw)
+        rows.append([pos[0] + offset[0], pos[1] + offset[1], pos[2] + offset[2], 0.0, 0.0, math.sin(h), math.cos(h)])
+    return np.array(rows).reshape(-1, 7)
+
+
 def snap_cost(coef: np.ndarray, dur: np.ndarray) -> np.ndarray:
     """J = sum_seg int_0^T (p^(k))^2 dt per axis, k = ncoef/2, by exact integration of the
     squared k-th derivative polynomial.  coef [M,4,ncoef], dur [M] -> [4].  (The reference

@@ -296,6 +296,38 @@ def test_flatness_evaluator_against_reference(ctx7, golden):
     assert np.isnan(out).all()
 
 
+def test_get_nav_path_msg(ctx7, golden):
+    """trajectory_visualising.get_nav_path_msg (reference visualization.py:39-71) on the reference's
+    src/traj.csv and on a Pol_matrix file with the reference's skiprows quirk: poses against the
+    oracle's restatement (positions + offset, quaternion_from_euler(0, 0, -yaw))."""
+    from drone_path_planning_python_amd.trajectory_visualising import Trajectory, get_nav_path_msg, get_nav_path_msgs
+    from drone_path_planning_python_amd.nodes import msgs
+    tr = Trajectory()
+    tr.loadcsv(os.path.join(GOLDEN_DIR, "traj.csv"))
+    mat = np.loadtxt(os.path.join(GOLDEN_DIR, "traj.csv"), delimiter=",", skiprows=1, usecols=range(33))
+    offset = [0, 0, -0.5]                                       # scripts/path_vis.py:18-19
+    msg = get_nav_path_msg(tr, 0.1, offset, ctx=ctx7)
+    ref = O.nav_path_poses(mat, 0.1, offset)
+    assert msg.header.frame_id == "world" and len(msg.poses) == ref.shape[0] == len(np.arange(0, tr.duration, 0.1))
+    pos, quat = msgs.path_to_arrays(msg)
+    np.testing.assert_allclose(pos, ref[:, :3], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(quat, ref[:, 3:], rtol=1e-12, atol=1e-13)
+    # the visual node's own inputs: header-less Pol_matrix files read with skiprows=1 (first piece dropped)
+    trs, mats = [], []
+    for name in ("Pol_matrix_1.csv", "Pol_matrix_2.csv"):
+        t2 = Trajectory()
+        t2.loadcsv(os.path.join(GOLDEN_DIR, name))
+        assert t2.n_pieces() == 48
+        trs.append(t2)
+        mats.append(np.loadtxt(os.path.join(GOLDEN_DIR, name), delimiter=",", skiprows=1, usecols=range(33)))
+    out = get_nav_path_msgs(trs, 0.1, [[0, 0, -0.5], [0.1, 0, -0.5]], ctx=ctx7)
+    for m, mat2, off in zip(out, mats, ([0, 0, -0.5], [0.1, 0, -0.5])):
+        ref = O.nav_path_poses(mat2.astype(np.float64), 0.1, off)
+        pos, quat = msgs.path_to_arrays(m)
+        np.testing.assert_allclose(pos, ref[:, :3], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(quat, ref[:, 3:], rtol=1e-11, atol=1e-11)
+
+
 def test_flatness_evaluator_batch_on_solved_swarm(ctx7):
     from drone_path_planning_python_amd.synthetic import swarm
     wp, t = swarm(31, 9, 6)

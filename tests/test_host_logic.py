@@ -194,3 +194,24 @@ def test_bench_accounting_helpers():
     assert bench.METRIC.startswith("minimum-snap trajectories/sec")
     tr, kn = bench.pmc_traffic(256, 10, 7)
     assert tr is None or tr > 788480 * 0.9
+
+
+def test_nav_path_quaternion_and_arrays():
+    """Host side of get_nav_path_msg: quaternion_from_euler(0, 0, yaw) for the 'sxyz' axes and the
+    Trajectory -> array conversion (no GPU: the evaluator itself is tested with -m gpu)."""
+    from drone_path_planning_python_amd.trajectory_visualising import Trajectory, quaternion_from_yaw, trajectory_arrays
+    for yaw in (0.0, 0.3, -2.5, math.pi):
+        q = quaternion_from_yaw(yaw)
+        assert q[0] == 0.0 and q[1] == 0.0
+        assert abs(q[2] - math.sin(yaw / 2)) < 1e-15 and abs(q[3] - math.cos(yaw / 2)) < 1e-15
+        # the rotation it encodes turns x into (cos yaw, sin yaw, 0)
+        v = O.quat_rotate(np.array(q), np.array([1.0, 0.0, 0.0]))
+        np.testing.assert_allclose(v, [math.cos(yaw), math.sin(yaw), 0.0], atol=1e-15)
+    tr = Trajectory()
+    tr.loadcsv(os.path.join(GOLDEN_DIR, "traj.csv"))
+    coef, dur = trajectory_arrays(tr)
+    mat = np.loadtxt(os.path.join(GOLDEN_DIR, "traj.csv"), delimiter=",", skiprows=1, usecols=range(33))
+    np.testing.assert_array_equal(coef[0].reshape(-1, 32), mat[:, 1:])
+    np.testing.assert_array_equal(dur[0], mat[:, 0])
+    ref = O.nav_path_poses(mat, 0.5)
+    assert ref.shape == (len(np.arange(0, tr.duration, 0.5)), 7)
