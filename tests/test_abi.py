@@ -73,3 +73,16 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         _lib.load()
     monkeypatch.undo()
     importlib.reload(_lib)
+
+
+def test_prefetch_wait_counts_match_the_code_object():
+    """tools/check_prefetch_isa.py: the hand-counted `s_waitcnt vmcnt(N)` of the persistent solve kernel
+    against the store instructions the compiler actually emitted (msnap_solve.o of this build)."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "drone_path_planning_python_amd", "csrc", "msnap_solve.o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no object file / ROCm LLVM tools here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_isa.py"), obj],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
