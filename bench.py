@@ -60,9 +60,6 @@ HBM_COPY_GBS = 6290.0
 VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
 PAIR_OPS = 9                   # 3 differences, 3 products, 2 sums, 1 minimum per pair and sample
-# vector instructions of one point-triangle test in mesh_sweep_kernel's code object, all closest-point
-# regions together (a wave whose samples fall into several regions walks all of them)
-MESH_TEST_OPS = 290
 
 
 def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:

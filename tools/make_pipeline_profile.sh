@@ -1,20 +1,23 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: rocprofv3 kernel stats of the config-3 / config-4 pipelines (solve -> sample ->
-# all-gather -> pairwise pass -> mesh sweep) and of the streaming kernels -> gpurun_out/pipeline_<tag>/
+# Runs ON THE GPU BOX: rocprofv3 kernel stats of the configs[2] / configs[3] pipelines on the pinned
+# formation fixtures (a8 -> solve -> sample -> pairwise pass -> sweep against the reference's STL scene)
+# and of the streaming kernels -> gpurun_out/pipeline_<tag>/
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/pipeline_${TAG}
 rm -rf "$OUT" && mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -- python3 tools/formation_pipeline.py --reps 30 > $OUT/config3.json 2> $OUT/c3.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 tools/formation_pipeline.py --segments 20 --mesh --reps 30 > $OUT/config4.json 2> $OUT/c4.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -- python3 tools/formation_pipeline.py --config 2 --reps 30 > $OUT/config2.json 2> $OUT/c2.err || { tail -3 $OUT/c2.err; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -- python3 tools/formation_pipeline.py --config 3 --reps 30 > $OUT/config3.json 2> $OUT/c3.err || { tail -3 $OUT/c3.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/aux -- python3 tools/aux_bench.py > $OUT/aux_bench.txt 2> $OUT/aux.err || exit 1
+# vector-instruction counts of the two collision kernels on the same workload (bench.py's mesh roofline)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 tools/formation_pipeline.py --config 3 --reps 10 > /dev/null 2> $OUT/pmc3.err || exit 1
 python3 - "$OUT" <<'PY'
-import csv, glob, sys
+import csv, glob, json, sys, collections
 out = sys.argv[1]
 with open(out + "/pipeline_summary.md", "w") as f:
-    for tag, title in (("c3", "configs[2]: 4096 drones x 10 segments, 91 samples, pairwise pass"),
-                       ("c4", "configs[3]: 4096 drones x 20 segments, 96 samples, pairwise pass + 56-triangle mesh sweep"),
+    for tag, title in (("c2", "configs[2]: 4096 drones x 10 segments (formation fixture), 91 samples, pairwise pass"),
+                       ("c3", "configs[3]: 4096 drones x 20 segments (formation fixture), 96 samples, pairwise pass + 68-triangle STL scene"),
                        ("aux", "streaming kernels at 2^18 drones x 10 segments (tools/aux_bench.py)")):
         path = glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True)[0]
         f.write(f"### {title}\n\n| kernel | calls | mean us | min us | max us |\n|---|---|---|---|---|\n")
@@ -25,6 +28,18 @@ with open(out + "/pipeline_summary.md", "w") as f:
             f.write("| `%s` | %s | %.1f | %.1f | %.1f |\n" % (name, r["Calls"], float(r["AverageNs"]) / 1e3,
                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
         f.write("\n")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in glob.glob(f"{out}/pmc3/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(fn)):
+            for k in ("mesh_sweep_kernel", "collide_span_kernel", "sample_kernel"):
+                if k in r["Kernel_Name"]:
+                    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    json.dump(counters, open(out + "/pmc_counters.json", "w"), indent=1)
+    f.write("### PMC counters per launch, configs[3] workload (mean)\n\n| kernel | counter | value |\n|---|---|---|\n")
+    for k, cs in sorted(counters.items()):
+        for c, v in sorted(cs.items()):
+            f.write(f"| `{k}` | {c} | {v:.6g} |\n")
 PY
 cat $OUT/pipeline_summary.md
-rm -rf $OUT/c3 $OUT/c4 $OUT/aux
+rm -rf $OUT/c2 $OUT/c3 $OUT/aux $OUT/pmc3

@@ -3,7 +3,7 @@
 #   bash tools/make_profiles.sh r01
 # Writes gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/profiles_${TAG}
 rm -rf "$OUT" && mkdir -p "$OUT"
@@ -17,14 +17,14 @@ echo "== 2. un-profiled bench line (the number to quote)"
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 
 echo "== 3. HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), per workload"
-HEAD="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-saturated --no-shared-grid"
-SAT="--no-graph --drones 1048576 --steps 5 --warmup 2 --no-cpu-baseline --no-saturated --no-shared-grid"
+HEAD="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-saturated --no-shared-grid --no-configs --no-end-to-end"
+SAT="--no-graph --drones 1048576 --steps 5 --warmup 2 --no-cpu-baseline --no-saturated --no-shared-grid --no-configs --no-end-to-end"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_256x10o7_$C -- python3 bench.py $HEAD > /dev/null 2> $OUT/pmc_h_$C.err || { tail -5 $OUT/pmc_h_$C.err; exit 1; }
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_1048576x10o7_$C -- python3 bench.py $SAT > /dev/null 2> $OUT/pmc_s_$C.err || { tail -5 $OUT/pmc_s_$C.err; exit 1; }
 done
 echo "== 4. SQ counters (all kernels of the default command: solve variants + the K2 MFMA GEMM)"
-ALL="--no-graph --steps 100 --warmup 10 --no-cpu-baseline"
+ALL="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-end-to-end"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_all_sq1 -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_sq1.err || exit 1
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_all_sq2 -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_sq2.err || exit 1
 rocprofv3 --pmc GRBM_GUI_ACTIVE TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr --kernel-trace --output-format csv -d $OUT/pmc_all_mem -- python3 bench.py $ALL > /dev/null 2> $OUT/pmc_mem.err || exit 1
