@@ -747,30 +747,38 @@ collide_short_kernel(const double *__restrict__ prow, const double *__restrict__
   hit[r] = (dist < 2.0 * radius) ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(kWave)
+// One workgroup per 64 rows, kMergeParts sub-groups of 64 lanes: sub-group q sweeps every kMergeParts-th
+// partial entry of its rows (a drone has a few hundred of them: swept by one thread the kernel is 28 us of
+// dependent loads at 4096 drones), the sub-groups' candidates are folded through LDS.
+constexpr int kMergeParts = 8;
+__global__ void __launch_bounds__(kWave * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
                      double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= g.R) return;
+  __shared__ double sD[kMergeParts][kWave];
+  __shared__ int sJ[kMergeParts][kWave];
+  const int lane = threadIdx.x & (kWave - 1), q = threadIdx.x / kWave;
+  const int r_raw = blockIdx.x * kWave + lane;
+  const int r = r_raw < g.R ? r_raw : g.R - 1;
   double best = INFINITY;
   int bj = -1;
-  constexpr int U = 8;      // entries fetched per round: the loads of a round are independent
+  constexpr int U = 4;      // entries fetched per round: the loads of a round are independent
   auto sweep = [&](const double *pd, const int32_t *pj, size_t pitch, int n) {
-    for (int s0 = 0; s0 < n; s0 += U) {
+    for (int s0 = q; s0 < n; s0 += U * kMergeParts) {
       double v[U];
       int j[U];
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
-        const int s = s0 + q < n ? s0 + q : n - 1;
-        v[q] = pd[(size_t)s * pitch];
-        j[q] = s0 + q < n ? pj[(size_t)s * pitch] : -1;
+      for (int k = 0; k < U; ++k) {
+        const int sidx = s0 + k * kMergeParts;
+        const int sc = sidx < n ? sidx : n - 1;
+        v[k] = pd[(size_t)sc * pitch];
+        j[k] = sidx < n ? pj[(size_t)sc * pitch] : -1;
       }
 #pragma unroll
-      for (int q = 0; q < U; ++q) {
-        if (j[q] >= 0 && (v[q] < best || (v[q] == best && j[q] < bj))) {
-          best = v[q];
-          bj = j[q];
+      for (int k = 0; k < U; ++k) {
+        if (j[k] >= 0 && (v[k] < best || (v[k] == best && j[k] < bj))) {
+          best = v[k];
+          bj = j[k];
         }
       }
     }
@@ -784,10 +792,24 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
     // column side: the row blocks before this drone's own
     if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I);
   }
-  const double dist = sqrt(best);
-  min_dist[r] = dist;
-  partner[r] = bj;
-  hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+  sD[q][lane] = best;
+  sJ[q][lane] = bj;
+  __syncthreads();
+  if (q == 0 && r_raw < g.R) {
+#pragma unroll
+    for (int k = 1; k < kMergeParts; ++k) {
+      const double v = sD[k][lane];
+      const int j = sJ[k][lane];
+      if (j >= 0 && (v < best || (v == best && j < bj))) {
+        best = v;
+        bj = j;
+      }
+    }
+    const double dist = sqrt(best);
+    min_dist[r] = dist;
+    partner[r] = bj;
+    hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+  }
 }
 
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
@@ -805,7 +827,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.sym = 0;
     g.upw = 1;
     g.total = 0;
-    hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream,
+    hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
                        (const int32_t *)nullptr, radius, min_dist, partner, hit);
     MSNAP_HIP(ctx, hipGetLastError());
@@ -854,8 +876,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream, pos_rows, pos_cols, g,
                      pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream, pd, pj, g,
-                     cd, ci, radius, min_dist, partner, hit);
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0,
+                     ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
