@@ -524,6 +524,8 @@ def run_solve_config(env, N, M, order, reps, warm, label):
         "reps": reps, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": {"solve": kus}, "solve_failures": cnt[0], "max_norm_rel_err_vs_oracle": mx[2],
         "stages": {"solve": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm",
+                             "algorithmic_bytes_per_launch": algorithmic_bytes(n_max, M, order),
+                             "traffic": pmc_traffic(n_max, M, order)[0],
                              "frac": algorithmic_bytes(n_max, M, order) / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS}},
     }
 
