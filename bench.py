@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                box's host cores on a bounded sample: B0 (one dense LU per axis, as the
                reference) and B1 (one LU for the four right-hand sides), one thread and all cores
   configs      every BASELINE.json config on this many GPUs, each with per-stage microseconds
-               (HIP events on the launching stream, max over ranks), roofline fraction and bound:
+               (HIP events on the launching stream, median over the repetitions, max over ranks), roofline fraction and bound:
                  [1] 256 x 10 (the headline again)
                  [2] 4096 x 10: solve -> sample -> all-gather -> pairwise formation pass
                  [3] 4096 x 20: the same + sweep against resources/stl/env-scene-hole.stl and
@@ -417,7 +417,8 @@ def run_formation_config(cfg, env, reps, warm):
     wall = time.perf_counter() - t0
     if use_pg:
         dist.barrier()
-    stage_us = [sum(ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)) / reps * 1e3 for k in range(nst)]
+    # median over the repetitions: one preempted launch must not pass for a stage's time
+    stage_us = [float(np.median([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)])) * 1e3 for k in range(nst)]
     # the shared-grid GEMM on the same shard, outside the pipeline (the inputs are on the reference's uniform grid)
     ctx.prepare_grid(t)
     gcoef = torch.empty((n, M, 4, 8), dtype=torch.float64, device=device)
