@@ -1263,12 +1263,11 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     // persistent waves (all resident at once) so that tile k+1's inputs can be prefetched during tile k
     const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg);
     // Waves beyond the resident set (8 or 4 per CU) are started by the hardware as others retire, which
-    // staggers the tiles' load / compute / store phases across the chip: measured at 2^19..2^20 drones,
-    // order 7 M <= 10: 0.681 ms with exactly the resident set, 0.647 ms with 8x as many (4 tiles per wave
-    // still leave the cross-tile prefetch its work); order 9 M > 10: 1.96 -> 1.47 ms; the other two
-    // instances do not care (order 7 M > 10) or lose 1-2 % (order 9 M <= 10) and keep the resident set.
-    const bool oversubscribe = (K <= 4) == (M <= kRegMaxSeg);
-    int grid = ctx->n_cu * (two_per_simd ? 8 : 4) * (oversubscribe ? 8 : 1);
+    // staggers the tiles' load / compute / store phases across the chip: 8x the resident set everywhere
+    // (2^19..2^20 drones, order 7 M <= 10: 0.681 -> 0.647 ms, 4 tiles per wave still leave the cross-tile
+    // prefetch its work; order 9 M > 10: 1.96 -> 1.55 ms; 65 536 drones, tools/reg_grid_probe.py: order 9
+    // M <= 10 73.5 -> 71 us, order 7 M > 10 106 -> 101 us; the saturated launches of those two do not care).
+    int grid = ctx->n_cu * (two_per_simd ? 8 : 4) * 8;
     if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;   // msnap_set_option: tests walk several tiles per wave
     if (grid > ntiles) grid = ntiles;
     if (M <= kRegMaxSeg)
