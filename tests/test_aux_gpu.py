@@ -159,6 +159,40 @@ def test_formation_collide_rows_not_among_columns(ctx7):
         assert md[q] == np.sqrt(d2.min()) and partner[q] == int(np.argmin(d2))
 
 
+@pytest.mark.parametrize("n,s", [(1, 8), (2, 6), (3, 5), (65, 6), (64, 7), (129, 1)])
+def test_formation_collide_small_edges(ctx7, n, s):
+    """One drone (nobody to meet: +inf / -1 / no hit), exactly one sample chunk, fewer samples than a chunk
+    (the plain-loop kernel), one row more than a row block."""
+    import c_oracle
+    rng = np.random.default_rng(n * 31 + s)
+    pos = rng.uniform(-1.0, 1.0, size=(n, s, 3))
+    md, partner, hit = ctx7.formation_collide(pos, pos, 0.2)
+    rmd, rpartner, rhit = c_oracle.formation_collide(pos, 0.2)
+    np.testing.assert_array_equal(md, rmd)
+    np.testing.assert_array_equal(partner, rpartner)
+    np.testing.assert_array_equal(hit, rhit)
+    if n == 1:
+        assert np.isinf(md[0]) and partner[0] == -1 and not hit[0]
+
+
+@pytest.mark.parametrize("n,s,t", [(3, 10, 0), (5, 1, 1), (7, 64, 65), (4, 200, 130), (2, 2100, 12)])
+def test_mesh_sweep_edges(ctx7, n, s, t):
+    """No triangles (+inf, no hit), a single sample, more triangles than one lane group (65, 130), more samples
+    than one workgroup pass (2100): the exact cull must not change any distance."""
+    import c_oracle
+    rng = np.random.default_rng(n * 17 + s + t)
+    pos = rng.uniform(-3.0, 3.0, size=(n, s, 3))
+    tris = rng.uniform(-4.0, 4.0, size=(t, 3, 3))
+    if t > 3:
+        tris[3, 1] = tris[3, 0]                     # a degenerate triangle (two equal vertices)
+    md, hit = ctx7.mesh_sweep(pos, tris, 0.4)
+    rmd, rhit = c_oracle.mesh_sweep(pos, tris, 0.4)
+    np.testing.assert_allclose(md, rmd, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(hit, rhit)
+    if t == 0:
+        assert np.isinf(md).all() and not hit.any()
+
+
 def test_mesh_sweep_against_oracle(ctx7, tmp_path):
     from drone_path_planning_python_amd import stl
     wall = stl.box_mesh((-2, 3.9, 0), (2, 4.1, 1.6))        # env-scene-ltu-experiment.stl's box
