@@ -502,7 +502,9 @@ struct CollideGeom {
   int os, oe;               // own range: the columns [os, oe) that are this call's rows (os == oe: none)
   int sym;                  // own-range pairs evaluated once
   int n_rb;                 // row blocks
-  int upw;                  // (row block, column) units per wave
+  int upw;                  // (row block, column) units per share
+  int upw_tail;             // units per share behind `split` (smaller shares even out the end of the launch)
+  long long split;          // first unit of the tail shares (a multiple of upw)
   long long total;          // units of the launch
 };
 
@@ -510,6 +512,16 @@ struct CollideGeom {
 // with it row block I skips the own-range columns before its own first one
 __device__ __host__ __forceinline__ long long collide_ustart(const CollideGeom &g, int I) {
   return g.sym ? (long long)I * g.Cn - (long long)kRowBlock * I * (I - 1) / 2 : (long long)I * g.Cn;
+}
+
+// share w covers the units [collide_share_begin(w), collide_share_begin(w + 1)) of the line
+__device__ __host__ __forceinline__ long long collide_share_begin(const CollideGeom &g, long long w) {
+  const long long w1 = g.split / g.upw;                  // shares of the head
+  const long long u = w <= w1 ? w * g.upw : g.split + (w - w1) * g.upw_tail;
+  return u < g.total ? u : g.total;
+}
+__device__ __host__ __forceinline__ long long collide_share_of(const CollideGeom &g, long long u) {
+  return u < g.split ? u / g.upw : g.split / g.upw + (u - g.split) / g.upw_tail;
 }
 
 // 6 samples of a column drone = 18 contiguous doubles in scalar registers.  The loads are issued by
@@ -662,8 +674,8 @@ collide_span_kernel(const double *__restrict__ prow, const double *__restrict__ 
   __shared__ double sFold[CB * kWave];
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
-  long long u = (long long)w * g.upw;
-  const long long u_end = u + g.upw < g.total ? u + g.upw : g.total;
+  long long u = collide_share_begin(g, w);
+  const long long u_end = collide_share_begin(g, (long long)w + 1);
   if (u >= u_end) return;
   // the row block the share starts in
   int I = 0;
@@ -786,7 +798,7 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   if (g.total > 0) {
     // row side: the shares that met this drone's row block
     const int I = r / kRowBlock;
-    const long long wf = collide_ustart(g, I) / g.upw, wl = (collide_ustart(g, I + 1) - 1) / g.upw;
+    const long long wf = collide_share_of(g, collide_ustart(g, I)), wl = collide_share_of(g, collide_ustart(g, I + 1) - 1);
     const size_t first = ((size_t)wf + I) * kRowBlock + (r - I * kRowBlock);
     sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1));
     // column side: the row blocks before this drone's own
@@ -825,7 +837,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     // nobody to collide with: the merge of nothing writes inf / -1 / 0
     g.os = g.oe = 0;
     g.sym = 0;
-    g.upw = 1;
+    g.upw = g.upw_tail = 1;
+    g.split = 0;
     g.total = 0;
     hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
@@ -863,7 +876,16 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // the row-side partial buffer holds one 64-row entry per (wave, row block) pair: bound it
   while (((g.total + upw - 1) / upw + g.n_rb) * kRowBlock * 12 > ((long long)512 << 20)) upw *= 2;
   g.upw = (int)upw;
-  waves = (g.total + upw - 1) / upw;
+  // The last part of the line goes out in half-size shares: when the queue runs dry the SIMDs finish
+  // within half a share of each other.  Only worth it while a SIMD sees few shares (at 4096 drones: 8).
+  g.upw_tail = (int)upw;
+  g.split = (g.total + upw - 1) / upw * upw;
+  const long long shares = (g.total + upw - 1) / upw;
+  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares < (long long)ctx->n_cu * 4 * 24) {
+    g.upw_tail = kColBlock / 2;
+    g.split = shares * 3 / 4 * upw;
+  }
+  waves = g.split / upw + (g.total - g.split + g.upw_tail - 1) / g.upw_tail;
   if (upw > 0x3fffffff || waves > 0x7fffffff) return MSNAP_EINVAL;
   const size_t part_entries = ((size_t)waves + g.n_rb) * kRowBlock;
   const size_t centries = g.sym ? cpart_entries : 0;

@@ -28,9 +28,9 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ref = None
     for variant in (0,):
-        for wpc in (0, 16, 64):
+        for wpc in (64, 0, 64, 0):
             ctx.set_option("collide_waves_per_cu", wpc)
-            for _ in range(3):
+            for _ in range(25):
                 ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
