@@ -451,7 +451,7 @@ def run_formation_config(cfg, env, reps, warm):
                     f"{synthetic.SAMPLE_DT} s" + (f", {tris.shape[0]}-triangle scene (env-scene-hole.stl + "
                                                    f"env-scene-ltu-experiment.stl)" if tris is not None else ""),
         "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling)", "rccl_ranks": world,
-        "reps": reps, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
+        "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": st,
         "solve_failures": cnt[0], "pairwise_hits": cnt[1], "pairwise_hits_fixture": int(fix[f"cfg{cfg}_pair_hit_idx"].size),
         "stages": {
@@ -522,7 +522,7 @@ def run_solve_config(env, N, M, order, reps, warm, label):
     return {
         "workload": f"{label}: {N} drones x {M} segments, order {order}, per-drone random time grids",
         "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling, no collective)",
-        "reps": reps, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
+        "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": {"solve": kus}, "solve_failures": cnt[0], "max_norm_rel_err_vs_oracle": mx[2],
         "stages": {"solve": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm",
                              "algorithmic_bytes_per_launch": algorithmic_bytes(n_max, M, order),
@@ -600,9 +600,10 @@ def main():
         env = dict(torch=torch, dist=dist, ctx7=ctx7, ctx9=ctx9, device=device, rank=rank, world=world,
                    use_pg=use_pg, red_dev=red_dev,
                    coll=dist if args.backend == "nccl" else HostGather(dist))
-        c2 = run_formation_config(2, env, reps, 5)
-        c3 = run_formation_config(3, env, reps, 5)
-        c4 = run_solve_config(env, 65536, 10, 9, reps, 10, "configs[4]")
+        # ~15 ms of the same work first: the GPU's clocks settle over tens of milliseconds of load
+        c2 = run_formation_config(2, env, reps, 40)
+        c3 = run_formation_config(3, env, reps, 40)
+        c4 = run_solve_config(env, 65536, 10, 9, reps, 40, "configs[4]")
         configs = {"2": c2, "3": c3, "4": c4}
         for c in (ctx7, ctx9):
             if c is not ctx:
