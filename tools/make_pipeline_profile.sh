@@ -10,6 +10,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2 -- python3 tools/formation_pipeline.py --config 2 --reps 30 > $OUT/config2.json 2> $OUT/c2.err || { tail -3 $OUT/c2.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -- python3 tools/formation_pipeline.py --config 3 --reps 30 > $OUT/config3.json 2> $OUT/c3.err || { tail -3 $OUT/c3.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/aux -- python3 tools/aux_bench.py > $OUT/aux_bench.txt 2> $OUT/aux.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p49 -- python3 tools/node_path49.py > $OUT/node_path49.txt 2> $OUT/p49.err || { tail -3 $OUT/p49.err; exit 1; }
 # vector-instruction counts of the two collision kernels on the same workload (bench.py's mesh roofline)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 tools/formation_pipeline.py --config 3 --reps 10 > /dev/null 2> $OUT/pmc3.err || exit 1
 python3 - "$OUT" <<'PY'
@@ -18,7 +19,8 @@ out = sys.argv[1]
 with open(out + "/pipeline_summary.md", "w") as f:
     for tag, title in (("c2", "configs[2]: 4096 drones x 10 segments (formation fixture), 91 samples, pairwise pass"),
                        ("c3", "configs[3]: 4096 drones x 20 segments (formation fixture), 96 samples, pairwise pass + 68-triangle STL scene"),
-                       ("aux", "streaming kernels at 2^18 drones x 10 segments (tools/aux_bench.py)")):
+                       ("aux", "streaming kernels at 2^18 drones x 10 segments (tools/aux_bench.py)"),
+                       ("p49", "the reference's live shape: 50-pose rigid-body path -> transform -> paths_to_pols, 2 drones x 49 segments (tools/node_path49.py)")):
         path = glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True)[0]
         f.write(f"### {title}\n\n| kernel | calls | mean us | min us | max us |\n|---|---|---|---|---|\n")
         for r in csv.DictReader(open(path)):
@@ -42,4 +44,4 @@ with open(out + "/pipeline_summary.md", "w") as f:
             f.write(f"| `{k}` | {c} | {v:.6g} |\n")
 PY
 cat $OUT/pipeline_summary.md
-rm -rf $OUT/c2 $OUT/c3 $OUT/aux $OUT/pmc3
+rm -rf $OUT/c2 $OUT/c3 $OUT/aux $OUT/pmc3 $OUT/p49
