@@ -349,9 +349,18 @@ __global__ void __launch_bounds__(256)
 flat_eval_kernel(const double *__restrict__ coef, const double *__restrict__ dur, const double *__restrict__ ts,
                  int N, int M, int S, double *__restrict__ out) {
 #pragma clang fp contract(off)
+  // A workgroup's 256 (drone, instant) items own 256 * 13 CONSECUTIVE output doubles: they go through an LDS
+  // image (stride 13 is odd: conflict-free) and leave as contiguous 8-byte-per-lane runs instead of 13 stores
+  // at a 104-byte stride per lane.
+  __shared__ double image[256 * 13];
   const size_t total = (size_t)N * S;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
+  const size_t span = (size_t)gridDim.x * blockDim.x;
+  const size_t trips = (total + span - 1) / span;      // the same for every thread: the barriers below are uniform
+  for (size_t trip = 0; trip < trips; ++trip) {
+    const size_t block_base = trip * span + (size_t)blockIdx.x * blockDim.x;
+    const size_t idx = block_base + threadIdx.x;
+    double *o = image + threadIdx.x * 13;
+    if (idx < total) {
     const int d = (int)(idx / S);
     const int s = (int)(idx - (size_t)d * S);
     const double t = ts[s];
@@ -365,12 +374,10 @@ flat_eval_kernel(const double *__restrict__ coef, const double *__restrict__ dur
         else acc_t = acc_t + Ti;
       }
     }
-    double *o = out + idx * 13;
     if (!(t >= 0.0) || seg < 0) {
 #pragma unroll
       for (int q = 0; q < 13; ++q) o[q] = __builtin_nan("");
-      continue;
-    }
+    } else {
     const double tl = t - acc_t;
     const double *c = coef + ((size_t)d * M + seg) * 4 * NC;
     double px, vx, ax, jx, py, vy, ay, jy, pz, vz, az, jz, yaw, dyaw, q2, q3;
@@ -397,6 +404,16 @@ flat_eval_kernel(const double *__restrict__ coef, const double *__restrict__ dur
     o[10] = hx * xbx + hy * xby + hz * xbz;
     o[11] = zbz * dyaw;
     o[12] = yaw;
+    }
+    }
+    __syncthreads();
+    const size_t ebase = block_base * 13, nelem = total * 13;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const size_t e = (size_t)j * blockDim.x + threadIdx.x;
+      if (ebase + e < nelem) out[ebase + e] = image[e];
+    }
+    __syncthreads();
   }
 }
 
