@@ -86,6 +86,7 @@ class Context:
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         self._lock = threading.Lock()   # a context is not re-entrant (msnap.h)
+        self._glock = threading.RLock()  # the prepared grid is context state: prepare + solve as one step
         rc = self._lib.msnap_create(ctypes.byref(self._h), int(device_id), int(order), int(max_segments))
         if rc != 0:
             self._h = ctypes.c_void_p()
@@ -199,17 +200,26 @@ class Context:
         t, pt = _host(t, np.float64)
         if t.ndim != 1 or t.shape[0] < 2:
             raise ValueError("t must be [m], m >= 2")
-        with self._lock:
-            self._ck(self._lib.msnap_grid_prepare(self._h, t.shape[0] - 1, pt))
-        self._grid_m = t.shape[0]
-        self._grid_host = t.copy()
+        with self._glock:
+            with self._lock:
+                self._ck(self._lib.msnap_grid_prepare(self._h, t.shape[0] - 1, pt))
+            self._grid_m = t.shape[0]
+            self._grid_host = t.copy()
 
     def ensure_grid(self, t):
         """prepare_grid(t) unless the context already holds exactly this grid."""
         t = np.ascontiguousarray(t, dtype=np.float64)
-        g = getattr(self, "_grid_host", None)
-        if g is None or g.shape != t.shape or not np.array_equal(g, t):
-            self.prepare_grid(t)
+        with self._glock:
+            g = getattr(self, "_grid_host", None)
+            if g is None or g.shape != t.shape or not np.array_equal(g, t):
+                self.prepare_grid(t)
+
+    def solve_on_grid(self, t, wp, out=None):
+        """ensure_grid(t) + solve_grid(wp) as one step: two threads sharing a context (the node's
+        callback1 / callback2) cannot swap the grid between the two calls."""
+        with self._glock:
+            self.ensure_grid(t)
+            return self.solve_grid(wp, out=out)
 
     def prepare_grid_device(self, n_seg, t):
         with self._lock:
@@ -219,19 +229,20 @@ class Context:
 
     def solve_grid(self, wp, out=None):
         """wp [N, m, 4] on the prepared grid -> coef, dur, status (as solve_batch)."""
-        wp, pwp = _host(wp, np.float64)
-        m = getattr(self, "_grid_m", None)
-        if m is None:
-            _lib.check(self._lib, self._h, -7)
-        if wp.ndim != 3 or wp.shape[1:] != (m, 4):
-            raise ValueError(f"wp must be [N, {m}, 4] for the prepared grid")
-        N, M = wp.shape[0], m - 1
-        coef, dur, status = _out_arrays(out, ((N, M, 4, self.ncoef), (N, M), (N,)))
-        with self._lock:
-            self._ck(self._lib.msnap_solve_grid(self._h, N, pwp, coef.ctypes.data_as(ctypes.c_void_p),
-                                               dur.ctypes.data_as(ctypes.c_void_p),
-                                               status.ctypes.data_as(ctypes.c_void_p)))
-        return coef, dur, status
+        with self._glock:
+            wp, pwp = _host(wp, np.float64)
+            m = getattr(self, "_grid_m", None)
+            if m is None:
+                _lib.check(self._lib, self._h, -7)
+            if wp.ndim != 3 or wp.shape[1:] != (m, 4):
+                raise ValueError(f"wp must be [N, {m}, 4] for the prepared grid")
+            N, M = wp.shape[0], m - 1
+            coef, dur, status = _out_arrays(out, ((N, M, 4, self.ncoef), (N, M), (N,)))
+            with self._lock:
+                self._ck(self._lib.msnap_solve_grid(self._h, N, pwp, coef.ctypes.data_as(ctypes.c_void_p),
+                                                   dur.ctypes.data_as(ctypes.c_void_p),
+                                                   status.ctypes.data_as(ctypes.c_void_p)))
+            return coef, dur, status
 
     def solve_grid_device(self, n_drones, wp, coef, dur, status):
         with self._lock:

@@ -89,8 +89,7 @@ def paths_to_pols(paths: Sequence, ctx: Context | None = None):
     ctx = ctx or default_context(7)
     wp, t = paths_to_waypoints(paths)
     # every path of the node shares the uniform grid: one operator, one MFMA GEMM per batch
-    ctx.ensure_grid(t)
-    coef, dur, status = ctx.solve_grid(wp)
+    coef, dur, status = ctx.solve_on_grid(t, wp)
     for k in range(len(paths)):
         raise_for_status(int(status[k]), t)
     return ctx.pack_pol_matrix(coef, dur), coef, dur

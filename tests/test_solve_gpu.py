@@ -681,3 +681,43 @@ def test_options_api(ctx7):
     for name in ("solve_grid_waves", "gemm_grid_waves", "twist_max_drones", "no_twist", "collide_waves_per_cu"):
         assert ctx7.get_option(name) == 0
     assert ctx7.get_option("pipe_chunk_mb") == 64
+
+
+def test_two_threads_two_contexts_and_one_shared_context(golden):
+    """rospy runs callback1 / callback2 on separate threads (scripts/drones_pols_generator.py:102-103).
+    Independent contexts must run concurrently on their own streams, and one shared context must
+    serialise its callers (the wrapper's lock): every call returns the reference's coefficients."""
+    import threading
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.nodes import drones_pols_generator as dpg
+    from drone_path_planning_python_amd.nodes import msgs
+    wp49, ref49 = golden["path49_wp"], golden["path49_coef"]
+    wp2, t2, ref2 = golden["cfg2_wp"], golden["cfg2_t"], golden["cfg2_coef"]
+    errors = []
+
+    def worker(ctx, kind, reps):
+        try:
+            for _ in range(reps):
+                if kind == 0:      # the node's own call: a 50-pose path on the uniform grid (shared-grid GEMM)
+                    quat = np.zeros((50, 4))
+                    quat[:, 2] = np.sin(0.5 * wp49[:, 3])
+                    quat[:, 3] = np.cos(0.5 * wp49[:, 3])
+                    _, coef, _ = dpg.paths_to_pols([msgs.path_from_arrays(wp49[:, :3], quat)], ctx)
+                    assert norm_rel(coef[0], ref49) <= 1e-7
+                elif kind == 1:    # a batch on per-drone grids
+                    coef, _, status = ctx.solve_batch(wp2, t2)
+                    assert (status == 0).all() and norm_rel(coef, ref2) <= TIGHT
+                else:              # another shared grid on the same context (prepare + solve must be one step)
+                    coef, _, status = ctx.solve_on_grid(golden["cfg2s_t"], golden["cfg2s_wp"])
+                    assert (status == 0).all() and norm_rel(coef, golden["cfg2s_coef"]) <= TIGHT
+        except Exception as e:     # noqa: BLE001 (collected and re-raised on the main thread)
+            errors.append(repr(e))
+
+    with Context(order=7, max_segments=64) as a, Context(order=7, max_segments=64) as b:
+        threads = [threading.Thread(target=worker, args=(c, k, 40))
+                   for c, k in ((a, 0), (b, 1), (a, 1), (b, 0), (a, 2), (b, 2))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    assert not errors, errors
