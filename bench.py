@@ -444,7 +444,7 @@ def run_formation_config(cfg, env, reps, warm):
     n_max = max(swarm.shard_sizes(N, world))
     pair_alg = N * (N - 1) / 2 * S * PAIR_OPS                 # every unordered pair once
     # what the largest shard evaluates: its rows against the other shards' columns, its own block once per pair
-    pair_exec = (n_max * (N - n_max) + n_max * (n_max + 63) / 2) * S * PAIR_OPS
+    pair_exec = (n_max * (N - n_max) + n_max * (n_max + 127) / 2) * S * PAIR_OPS
     rep = {
         "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "

@@ -490,18 +490,20 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // samples s of |p_i(s) - p_j(s)|.  Semantics are this repo's: no reference
 // implementation exists.
 //
-// Arithmetic.  One lane per row drone (row blocks of 64); the column drone is wave-uniform, its
-// samples arrive through scalar loads and are SGPR operands of the 9 operations per pair and
-// sample (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the NumPy oracle, which
-// decides ties between equidistant formation neighbours -- and the minimum).  The running minima
-// of a block of 16 columns stay in registers over all samples.  A scalar load has only an
-// all-or-nothing wait, so a wave has ONE column fetch (6 samples, 54 operations) in flight while
-// it computes the previous one; the other waves of the SIMD (5 fit) cover the rest of the latency.
+// Arithmetic.  One lane per TWO row drones (row blocks of 128: rows lane and lane + 64); the column
+// drone is wave-uniform, its samples arrive through scalar loads and are SGPR operands of the 9
+// operations per pair and sample (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the
+// NumPy oracle, which decides ties between equidistant formation neighbours -- and the minimum).
+// The running minima of a block of 8 columns stay in registers over all samples.  A scalar load has
+// only an all-or-nothing wait, so a wave has ONE column fetch (6 samples, 2 x 54 operations) in
+// flight while it computes the previous one; the other waves of the SIMD (4 fit) cover the rest of
+// the latency.  The rows are read from a transposed image [sample][xyz][row] written once per call
+// (coalesced 512-byte loads; drone-major row loads would saturate the texture addresser).
 //
 // Work.  Columns that are also rows of this call (a single GPU: all of them; a shard: its own
 // 1/G) are evaluated ONCE per unordered pair: row block I meets the own-range columns from its
 // own first column on -- one-sidedly inside its diagonal block, two-sidedly behind it: d2 is
-// bitwise symmetric, so after such a block the per-column minima over the 64 rows (through a
+// bitwise symmetric, so after such a block the per-column minima over the 128 rows (through a
 // per-wave LDS image) are stored as partial results of the COLUMN drones.  The (row block,
 // column) units of the whole launch form one line -- row block after row block, the columns each
 // still has to meet -- and every wave takes an equal contiguous share of it: the waves finish
@@ -510,12 +512,14 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // minimum over a drone's row-side shares and column-side row blocks (lowest partner index wins
 // ties on both sides).
 // ------------------------------------------------------------------------------------
-constexpr int kRowBlock = kWave;
-constexpr int kColBlock = 16;     // column drones whose running minima a lane keeps in registers
+constexpr int kRowsPerLane = 2;
+constexpr int kRowBlock = kWave * kRowsPerLane;
+constexpr int kColBlock = 8;      // column drones whose running minima a lane keeps in registers (per row)
 constexpr int kSampleChunk = 6;   // samples per scalar fetch
 
 struct CollideGeom {
   int R, ro, Cn, S;         // rows, global index of row 0, columns, samples
+  int Rp;                   // rows of the transposed row image (R rounded up to whole row blocks)
   int os, oe;               // own range: the columns [os, oe) that are this call's rows (os == oe: none)
   int sym;                  // own-range pairs evaluated once
   int n_rb;                 // row blocks
@@ -560,12 +564,18 @@ struct ColChunk {
   __device__ __forceinline__ void wait(double &after) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+v"(after));
   }
-  // i is a compile-time constant after unrolling.  Every element has exactly ONE VALU user: a scalar
-  // value with two users is first copied into vector registers (which is why a lane owns one row, not two)
-  __device__ __forceinline__ double get(int i) const {
-    return i < 8 ? __hiloint2double((int)a[2 * i + 1], (int)a[2 * i])
-                 : i < 16 ? __hiloint2double((int)b[2 * (i - 8) + 1], (int)b[2 * (i - 8)])
-                          : __hiloint2double((int)c[2 * (i - 16) + 1], (int)c[2 * (i - 16)]);
+  // element i (a compile-time constant after unrolling) minus v, exactly rounded.  The difference is issued
+  // by hand with the scalar register pair as the first operand: a lane owns two rows, and left to the
+  // compiler a scalar value with two VALU users is first copied into vector registers (36 extra moves per
+  // fetch).
+  __device__ __forceinline__ double minus(int i, double v) const {
+    const unsigned long long x =
+        i < 8 ? ((unsigned long long)a[2 * i + 1] << 32) | a[2 * i]
+              : i < 16 ? ((unsigned long long)b[2 * (i - 8) + 1] << 32) | b[2 * (i - 8)]
+                       : ((unsigned long long)c[2 * (i - 16) + 1] << 32) | c[2 * (i - 16)];
+    double d;
+    asm("v_add_f64 %0, %1, -%2" : "=v"(d) : "s"(x), "v"(v));
+    return d;
   }
 };
 
@@ -576,60 +586,73 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 
 // One block of NC (a multiple of 4, <= kColBlock) consecutive columns [cj, cj + ncols) against the
-// wave's 64 rows: straight-line code over the columns -- with a branch inside the column loop the
+// wave's 128 rows: straight-line code over the columns -- with a branch inside the column loop the
 // scalar register sets cross basic blocks and the compiler copies every fetched value into vector
 // registers (36 extra VALU moves per fetch) -- so a short block takes the next instance up and
 // re-reads its last column instead of branching.
 template <int NC>
-__device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ pr0,
-                                              const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
-                                              bool live0, int grow0, int I, int lane, double *sFold, double &best0,
-                                              int &bestj0, double *__restrict__ cpart_d2,
+__device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ prowT,
+                                              const double *__restrict__ pcol, int cj,
+                                              int ncols, bool two_sided, bool live0, bool live1, int grow0, int grow1,
+                                              int I, int lane, double *sFold, int *sFoldI, double &best0, int &bestj0,
+                                              double &best1, int &bestj1, double *__restrict__ cpart_d2,
                                               int32_t *__restrict__ cpart_i) {
 #pragma clang fp contract(off)
   constexpr int CH = kSampleChunk;
   const int S = g.S;
   const int stride = S * 3;
-  double acc0[NC];
+  double acc0[NC], acc1[NC];
 #pragma unroll
-  for (int jj = 0; jj < NC; ++jj) acc0[jj] = INFINITY;
+  for (int jj = 0; jj < NC; ++jj) acc0[jj] = acc1[jj] = INFINITY;
   for (int sc = 0; sc < S; sc += CH) {
     // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
     // seeing a sample twice), so every chunk takes the wide scalar loads
     const int s0 = (S - sc < CH) ? S - CH : sc;
-    double ax[CH], ay[CH], az[CH];
+    double ax[CH], ay[CH], az[CH], bx[CH], by[CH], bz[CH];
+    // the rows come from the transposed image [sample][xyz][row]: the 64 lanes of a load read 512
+    // contiguous bytes (from the drone-major layout every lane would touch its own cache line, and with two
+    // rows per lane the texture addresser, not the VALU, would set the pace: TA_BUSY 79 %)
+    // (uniform base per load, lane offset in one register: no per-lane 64-bit address arithmetic)
+    const double *pt = prowT + (size_t)s0 * 3 * g.Rp;
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-      ax[q] = pr0[(size_t)(s0 + q) * 3 + 0];
-      ay[q] = pr0[(size_t)(s0 + q) * 3 + 1];
-      az[q] = pr0[(size_t)(s0 + q) * 3 + 2];
+      const double *px = pt + (size_t)(3 * q + 0) * g.Rp, *py = pt + (size_t)(3 * q + 1) * g.Rp,
+                   *pz = pt + (size_t)(3 * q + 2) * g.Rp;
+      ax[q] = px[lane];
+      ay[q] = py[lane];
+      az[q] = pz[lane];
+      bx[q] = px[lane + kWave];
+      by[q] = py[lane + kWave];
+      bz[q] = pz[lane + kWave];
     }
     // one running pointer walks the block's columns; `nvalid` is made opaque per chunk so that the
     // per-column strides are not hoisted out of the sample loop into spilled scalar registers
     int nvalid = ncols;
     asm volatile("" : "+s"(nvalid));
     const double *pc = pcol + ((size_t)cj * S + s0) * 3;
-    auto consume = [&](double &m0, const ColChunk &k) {
+    auto consume = [&](double &m0, double &m1, const ColChunk &k) {
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
-        const double dx0 = k.get(3 * q + 0) - ax[q], dy0 = k.get(3 * q + 1) - ay[q], dz0 = k.get(3 * q + 2) - az[q];
+        const double dx0 = k.minus(3 * q + 0, ax[q]), dy0 = k.minus(3 * q + 1, ay[q]), dz0 = k.minus(3 * q + 2, az[q]);
+        const double dx1 = k.minus(3 * q + 0, bx[q]), dy1 = k.minus(3 * q + 1, by[q]), dz1 = k.minus(3 * q + 2, bz[q]);
         m0 = __builtin_fmin(dx0 * dx0 + dy0 * dy0 + dz0 * dz0, m0);
+        m1 = __builtin_fmin(dx1 * dx1 + dy1 * dy1 + dz1 * dz1, m1);
       }
     };
     // two register sets alternate: the loads of column j+1 are issued right after the wait for
-    // column j and fly during its 6 x 9 VALU operations
+    // column j and fly during its 2 x 6 x 9 VALU operations
     ColChunk ca, cb2;
     ca.fetch(pc);
 #pragma unroll
     for (int jj = 0; jj < NC; jj += 2) {
       pc += (jj + 1 < nvalid) ? stride : 0;
-      ca.wait(acc0[jj > 0 ? jj - 1 : 0]);
+      ca.wait(acc1[jj > 0 ? jj - 1 : 0]);
       cb2.fetch(pc);
-      consume(acc0[jj], ca);
+      consume(acc0[jj], acc1[jj], ca);
       pc += (jj + 2 < nvalid) ? stride : 0;
-      cb2.wait(acc0[jj]);
+      cb2.wait(acc1[jj]);
       if (jj + 2 < NC) ca.fetch(pc);
-      consume(acc0[jj + 1], cb2);
+      consume(acc0[jj + 1], acc1[jj + 1], cb2);
     }
   }
   // row side: columns ascend, so the lowest index wins a tie
@@ -637,36 +660,47 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
   for (int jj = 0; jj < NC; ++jj) {
     const int j = cj + jj;
     acc0[jj] = (j == grow0 || jj >= ncols) ? INFINITY : acc0[jj];
+    acc1[jj] = (j == grow1 || jj >= ncols) ? INFINITY : acc1[jj];
     if (acc0[jj] < best0) {
       best0 = acc0[jj];
       bestj0 = j;
     }
+    if (acc1[jj] < best1) {
+      best1 = acc1[jj];
+      bestj1 = j;
+    }
   }
   if (two_sided) {
-    // column side: min over the 64 rows of every column of the block, with the lowest row, through
-    // the LDS image [column][lane]; lane = 16 * part + column then scans a quarter of its column
-    // (rows ascend: strict '<' keeps the lowest on ties) and the four parts are folded with two
-    // exchanges.  Rows past the batch end replay row R-1 and must not win.
+    // column side: min over the 128 rows of every column of the block, with the lowest row.  Each lane
+    // first folds its own two rows (the lower row wins a tie); the 64 candidates of a column go through the
+    // LDS image [column][lane]; lane = 8 * part + column then scans an eighth of its column and the parts
+    // are folded with three exchanges.  Rows past the batch end replay row R-1 and must not win.
 #pragma unroll
-    for (int c = 0; c < NC; ++c) sFold[c * kWave + lane] = live0 ? acc0[c] : INFINITY;
+    for (int c = 0; c < NC; ++c) {
+      const double v0 = live0 ? acc0[c] : INFINITY, v1 = live1 ? acc1[c] : INFINITY;
+      const bool second = v1 < v0;
+      sFold[c * kWave + lane] = second ? v1 : v0;
+      sFoldI[c * kWave + lane] = second ? lane + kWave : lane;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    const int c = lane & (kColBlock - 1), part = lane >> 4;
+    const int c = lane & (kColBlock - 1), part = lane >> 3;
     double cm = INFINITY;
     int ci = 0;
     if (c < NC) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const double v = sFold[c * kWave + part * 16 + k];
-        if (v < cm) {
+      for (int k = 0; k < 8; ++k) {
+        const double v = sFold[c * kWave + part * 8 + k];
+        const int vi = sFoldI[c * kWave + part * 8 + k];
+        if (v < cm || (v == cm && vi < ci)) {
           cm = v;
-          ci = part * 16 + k;
+          ci = vi;
         }
       }
     }
 #pragma unroll
-    for (int mask = 16; mask <= 32; mask <<= 1) {
+    for (int mask = 8; mask <= 32; mask <<= 1) {
       const double other = shfl_xor_f64(cm, mask);
       const int oi = __shfl_xor(ci, mask);
       const bool take = (other < cm) | ((other == cm) & (oi < ci));
@@ -683,12 +717,37 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
   }
 }
 
-__global__ void __launch_bounds__(kWave, 5)
-collide_span_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, CollideGeom g,
+// The rows of a call as [sample][xyz][row] (row pitch Rp; the rows behind R replay row R - 1): 64 x 64
+// tiles through LDS, read along a drone's samples and written along the rows.
+__global__ void __launch_bounds__(256)
+collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t) {
+  constexpr int TE = 32;      // elements of a drone per tile (x 64 rows): 2.4 workgroups per CU at 4096 x 91
+  __shared__ double tile[64][TE + 1];
+  const int r0 = blockIdx.x * 64, e0 = blockIdx.y * TE;
+  {
+    const int tx = threadIdx.x & (TE - 1), ty = threadIdx.x / TE;
+#pragma unroll
+    for (int i = ty; i < 64; i += 256 / TE) {
+      const int r = min(r0 + i, R - 1), e = e0 + tx;
+      tile[i][tx] = e < E ? prow[(size_t)r * E + e] : 0.0;
+    }
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = ty; i < TE; i += 4) {
+    const int e = e0 + i;
+    if (e < E) prow_t[(size_t)e * Rp + r0 + tx] = tile[tx][i];
+  }
+}
+
+__global__ void __launch_bounds__(kWave, 4)
+collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
                     double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
                     int32_t *__restrict__ cpart_i) {
   constexpr int CB = kColBlock;
   __shared__ double sFold[CB * kWave];
+  __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
   long long u = collide_share_begin(g, w);
@@ -705,13 +764,13 @@ collide_span_kernel(const double *__restrict__ prow, const double *__restrict__ 
     // unit -> column: the columns left of the own range, then from the row block's own first column on
     const int diag0 = g.os + I * kRowBlock;                               // only meaningful with g.sym
     const int skip = g.sym ? I * kRowBlock : 0;                           // own-range columns not met
-    const int r0raw = I * kRowBlock + lane;
-    const bool live0 = r0raw < g.R;
-    const int r0 = live0 ? r0raw : g.R - 1;
-    const int grow0 = g.ro + r0;
-    const double *pr0 = prow + (size_t)r0 * g.S * 3;
-    double best0 = INFINITY;
-    int bestj0 = -1;
+    const int r0raw = I * kRowBlock + lane, r1raw = r0raw + kWave;
+    const bool live0 = r0raw < g.R, live1 = r1raw < g.R;
+    const int r0 = live0 ? r0raw : g.R - 1, r1 = live1 ? r1raw : g.R - 1;
+    const int grow0 = g.ro + r0, grow1 = g.ro + r1;
+    const double *prowT = prow_t + (size_t)I * kRowBlock;
+    double best0 = INFINITY, best1 = INFINITY;
+    int bestj0 = -1, bestj1 = -1;
     for (int ux = ua; ux < ue;) {
       // a block: up to CB consecutive columns that do not straddle a boundary of the line
       const int cj = (g.sym && ux >= g.os) ? ux + skip : ux;
@@ -727,18 +786,20 @@ collide_span_kernel(const double *__restrict__ prow, const double *__restrict__ 
       }
       const int ncols = lim < CB ? lim : CB;
       ux += ncols;
-      switch ((ncols + 3) >> 2) {
-        case 1: collide_block<4>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
-        case 2: collide_block<8>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
-        case 3: collide_block<12>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
-        default: collide_block<16>(g, pr0, pcol, cj, ncols, two_sided, live0, grow0, I, lane, sFold, best0, bestj0, cpart_d2, cpart_i); break;
-      }
+      if (ncols <= 4)
+        collide_block<4>(g, prowT, pcol, cj, ncols, two_sided, live0, live1, grow0, grow1, I, lane, sFold, sFoldI,
+                         best0, bestj0, best1, bestj1, cpart_d2, cpart_i);
+      else
+        collide_block<8>(g, prowT, pcol, cj, ncols, two_sided, live0, live1, grow0, grow1, I, lane, sFold, sFoldI,
+                         best0, bestj0, best1, bestj1, cpart_d2, cpart_i);
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
     const size_t id = (size_t)w + I;
     part_d2[id * kRowBlock + lane] = best0;
     part_j[id * kRowBlock + lane] = (best0 == INFINITY) ? -1 : bestj0;
+    part_d2[id * kRowBlock + kWave + lane] = best1;
+    part_j[id * kRowBlock + kWave + lane] = (best1 == INFINITY) ? -1 : bestj1;
   }
 }
 
@@ -779,7 +840,7 @@ collide_short_kernel(const double *__restrict__ prow, const double *__restrict__
 // One workgroup per 64 rows, kMergeParts sub-groups of 64 lanes: sub-group q sweeps every kMergeParts-th
 // partial entry of its rows (a drone has a few hundred of them: swept by one thread the kernel is 28 us of
 // dependent loads at 4096 drones), the sub-groups' candidates are folded through LDS.
-constexpr int kMergeParts = 8;
+constexpr int kMergeParts = 16;
 __global__ void __launch_bounds__(kWave * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
@@ -850,6 +911,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.Cn = n_cols;
   g.S = n_samples;
   g.n_rb = (n_rows + kRowBlock - 1) / kRowBlock;
+  g.Rp = g.n_rb * kRowBlock;
   if (n_cols == 0) {
     // nobody to collide with: the merge of nothing writes inf / -1 / 0
     g.os = g.oe = 0;
@@ -878,19 +940,18 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.sym = (rows_in_cols && n_rows > kRowBlock && cpart_entries * 12 <= ((size_t)256 << 20)) ? 1 : 0;
   g.upw = 1;
   g.total = collide_ustart(g, g.n_rb);
-  // Equal contiguous shares of the line, one 16-column block each.  Many small shares beat one share
-  // per resident wave: the dispatcher hands the next share to whichever SIMD frees a slot, which evens
-  // out the speed differences between SIMDs (4096 x 91: 384 us with 20 shares per CU, 305 us with 32;
-  // 8192 x 96: 1.46 -> 1.06 ms); shares of 4 or 8 columns lose more to the per-block row loads than
-  // they gain (2048 x 91: 125 -> 250 us); a share that ends inside a block pays for the whole block.
-  // "collide_waves_per_cu" (tuning tools) asks for fewer, longer shares.
+  // Equal contiguous shares of the line, one 8-column block (x 128 rows) each.  Many small shares beat one
+  // share per resident wave: the dispatcher hands the next share to whichever SIMD frees a slot, which
+  // evens out the speed differences between SIMDs; shares of 4 columns everywhere lose more to the
+  // per-block prologue and fold than they gain (4096 x 91: 288 -> 340 us); a share that ends inside a
+  // block pays for the whole block.  "collide_waves_per_cu" (tuning tools) asks for fewer, longer shares.
   long long upw = kColBlock;
   if (ctx->collide_waves_per_cu > 0) {
     upw = g.total / ((long long)ctx->n_cu * ctx->collide_waves_per_cu) / kColBlock * kColBlock;
     if (upw < kColBlock) upw = kColBlock;
   }
   long long waves;
-  // the row-side partial buffer holds one 64-row entry per (wave, row block) pair: bound it
+  // the row-side partial buffer holds one 128-row entry per (wave, row block) pair: bound it
   while (((g.total + upw - 1) / upw + g.n_rb) * kRowBlock * 12 > ((long long)512 << 20)) upw *= 2;
   g.upw = (int)upw;
   // The last part of the line goes out in half-size shares: when the queue runs dry the SIMDs finish
@@ -906,14 +967,21 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   if (upw > 0x3fffffff || waves > 0x7fffffff) return MSNAP_EINVAL;
   const size_t part_entries = ((size_t)waves + g.n_rb) * kRowBlock;
   const size_t centries = g.sym ? cpart_entries : 0;
-  int rc = ensure(ctx, ctx->stage[7], (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
+  const int E = n_samples * 3;
+  const size_t t_entries = (size_t)g.Rp * E;
+  int rc = ensure(ctx, ctx->stage[7],
+                  t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
-  double *pd = (double *)ctx->stage[7].p;
+  double *rows_t = (double *)ctx->stage[7].p;
+  double *pd = rows_t + t_entries;
   double *cd = pd + part_entries;
   int32_t *pj = (int32_t *)(cd + centries);
   int32_t *ci = pj + part_entries;
-  hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream, pos_rows, pos_cols, g,
-                     pd, pj, cd, ci);
+  hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
+                     n_rows, g.Rp, E, rows_t);
+  MSNAP_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream,
+                     (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);

@@ -83,7 +83,7 @@ int msnap_host_free(void *ptr);
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
- *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 16-column block per share)
+ *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 8-column x 128-row block per share)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
