@@ -27,30 +27,16 @@ inline size_t solve_scratch_words(int khalf, int n_seg) {
 // doubles of the LDS input stage (raw copy of the tile's waypoints and times)
 inline size_t solve_input_words(int n_seg) { return (size_t)16 * (n_seg + 1) * 5; }
 
-// s_waitcnt vmcnt(younger): returns once all but the `younger` most recent vector-memory operations
-// of the wave have completed (loads and stores share the counter on gfx950 and retire in order).
-// For hand-issued asm prefetch loads followed by a known number of stores.  The immediate must be
-// a constant, hence the (wave-uniform) switch; counts above the 6-bit field drain everything.
-#define MSNAP_VMCNT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-#define MSNAP_VMCNT_CASE8(a, b, c, d, e, f, g, h) \
-  MSNAP_VMCNT_CASE(a) MSNAP_VMCNT_CASE(b) MSNAP_VMCNT_CASE(c) MSNAP_VMCNT_CASE(d) \
-  MSNAP_VMCNT_CASE(e) MSNAP_VMCNT_CASE(f) MSNAP_VMCNT_CASE(g) MSNAP_VMCNT_CASE(h)
-__device__ __forceinline__ void wait_vmcnt_younger(int younger) {
-  switch (younger) {
-    MSNAP_VMCNT_CASE(1) MSNAP_VMCNT_CASE(2) MSNAP_VMCNT_CASE(3) MSNAP_VMCNT_CASE(4)
-    MSNAP_VMCNT_CASE(5) MSNAP_VMCNT_CASE(6) MSNAP_VMCNT_CASE(7)
-    MSNAP_VMCNT_CASE8(8, 9, 10, 11, 12, 13, 14, 15)
-    MSNAP_VMCNT_CASE8(16, 17, 18, 19, 20, 21, 22, 23)
-    MSNAP_VMCNT_CASE8(24, 25, 26, 27, 28, 29, 30, 31)
-    MSNAP_VMCNT_CASE8(32, 33, 34, 35, 36, 37, 38, 39)
-    MSNAP_VMCNT_CASE8(40, 41, 42, 43, 44, 45, 46, 47)
-    MSNAP_VMCNT_CASE8(48, 49, 50, 51, 52, 53, 54, 55)
-    MSNAP_VMCNT_CASE8(56, 57, 58, 59, 60, 61, 62, 63)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
+// s_waitcnt vmcnt(N): returns once all but the N most recent vector-memory operations of the wave have
+// completed (loads and stores share the counter on gfx950 and retire in order).  For hand-issued asm
+// prefetch loads followed by AT LEAST N stores; the immediate is a compile-time constant (a run-time
+// choice between immediates compiles into a flag dispatch with a static path around every wait, which
+// tools/check_prefetch_isa.py could not tell from a missing wait).
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "6-bit vmcnt field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-#undef MSNAP_VMCNT_CASE8
-#undef MSNAP_VMCNT_CASE
 
 // growable device buffer
 struct DevBuf {

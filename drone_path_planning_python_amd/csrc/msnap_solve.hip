@@ -306,9 +306,11 @@ __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__
                                                         size_t drone_stride, int nvalid, int lane,
                                                         double (&c)[NC], bool bad) {
   constexpr int NJ = NC / 2;
-  if (bad) {
+  // a failed drone is rare: one wave-uniform test instead of 2 * NC selects per segment
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+    asm volatile("" ::: "memory");   // keep the block a branch: the compiler would flatten it into selects again
 #pragma unroll
-    for (int m = 0; m < NC; ++m) c[m] = __builtin_nan("");
+    for (int m = 0; m < NC; ++m) c[m] = bad ? __builtin_nan("") : c[m];
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sTr[j * kTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
@@ -323,8 +325,11 @@ __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__
     const int a2 = within / NJ;
     const int j2 = within - a2 * NJ;
     const double2 v = sTr[j2 * kTrPitch + drone * 4 + a2];
-    bool ok = drone < nvalid;
-    if (ok) *reinterpret_cast<double2 *>(seg_base + (size_t)drone * drone_stride + within * 2) = v;
+    // The lanes past the batch end replay the tile's last valid drone (same inputs, same instruction
+    // stream, bitwise the same coefficients), so their slots are stored ON TOP of that drone's instead
+    // of being masked off: no exec-mask region and branch pair per store.
+    const int dst = drone < nvalid ? drone : nvalid - 1;
+    *reinterpret_cast<double2 *>(seg_base + (size_t)dst * drone_stride + within * 2) = v;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
@@ -332,59 +337,87 @@ __device__ __forceinline__ void store_segment_coalesced(double2 *sTr, double *__
 
 // Order-7 variant of the same idea without LDS: the 4 axis lanes of a drone hold a
 // 4 x 4 grid of 16-byte pieces (lane = axis, piece = coefficient pair) of the drone's
-// 256-byte block.  Two butterfly stages of quad-local exchanges (DPP quad_perm via
-// __shfl_xor 1 and 2) transpose the grid, after which store q of lane a carries
-// (axis q, pair a): the quad writes 64 contiguous bytes per instruction (whole
-// 64-byte segments), with no LDS round trip and no wait on the critical path.
-template <int CTRL>   // DPP quad_perm control: 0xB1 = lanes xor 1, 0x4E = lanes xor 2
-__device__ __forceinline__ double dpp_quad(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-template <int CTRL>
-__device__ __forceinline__ void quad_exchange(double &A, double &B, bool bit) {
-  // A: value whose piece-index bit is 0, B: bit is 1 (for this stage).  Scalars only:
-  // selecting between array elements would become a runtime-indexed (scratch) array.
-  const double send = bit ? A : B;
-  const double recv = dpp_quad<CTRL>(send);
-  const double na = bit ? recv : A;
-  const double nb = bit ? B : recv;
-  A = na;
-  B = nb;
-}
-
-// `blk` is this lane's drone-segment block (4 axes x 8 coefficients); all 4 axis lanes of a
-// quad must take the same path (the exchanges are quad-local).
-__device__ __forceinline__ void store_quad8_at(double *__restrict__ blk, bool ok, int a, const double (&c)[8],
-                                               bool bad) {
-  const double nanv = __builtin_nan("");
-  double p0x = bad ? nanv : c[0], p0y = bad ? nanv : c[1], p1x = bad ? nanv : c[2], p1y = bad ? nanv : c[3];
-  double p2x = bad ? nanv : c[4], p2y = bad ? nanv : c[5], p3x = bad ? nanv : c[6], p3y = bad ? nanv : c[7];
-  const bool b0 = (a & 1) != 0, b1 = (a & 2) != 0;
-  quad_exchange<0xB1>(p0x, p1x, b0);
-  quad_exchange<0xB1>(p0y, p1y, b0);
-  quad_exchange<0xB1>(p2x, p3x, b0);
-  quad_exchange<0xB1>(p2y, p3y, b0);
-  quad_exchange<0x4E>(p0x, p2x, b1);
-  quad_exchange<0x4E>(p0y, p2y, b1);
-  quad_exchange<0x4E>(p1x, p3x, b1);
-  quad_exchange<0x4E>(p1y, p3y, b1);
-  // now piece q = coefficient pair `a` of axis q
-  if (ok) {
-    double *o = blk + a * 2;
-    *reinterpret_cast<double2 *>(o + 0) = make_double2(p0x, p0y);
-    *reinterpret_cast<double2 *>(o + 8) = make_double2(p1x, p1y);
-    *reinterpret_cast<double2 *>(o + 16) = make_double2(p2x, p2y);
-    *reinterpret_cast<double2 *>(o + 24) = make_double2(p3x, p3y);
+// 256-byte block.  Two butterfly stages of quad-local exchanges transpose the grid, after
+// which store q of lane a carries (axis q, pair a): the quad writes 64 contiguous bytes per
+// instruction (whole 64-byte segments), with no LDS round trip and no wait on the critical
+// path.  A stage exchanges (A, B) pairs between lanes that differ in one bit of the axis:
+// lanes with the bit keep B and take the partner's B as their A, lanes without keep A and
+// take the partner's A as their B.  Written as select-with-DPP-source, one instruction per
+// dword and side:   B' = bit ? B : dpp(A)      (v_cndmask_b32_dpp, vcc = bit)
+//                   A' = !bit ? A : dpp(B)     (v_cndmask_b32_dpp, vcc = !bit)
+// -- 32 vector instructions per segment; select / v_mov_dpp / select, as the compiler emits
+// the same exchange from C++, takes 64 (a quarter of the order-7 backward sweep).
+// The leading s_nop covers the 2 wait states a DPP read needs after a VALU write.
+#define MSNAP_QCND(d, s0, s1, QP) \
+  "v_cndmask_b32_dpp %" #d ", %" #s0 ", %" #s1 ", vcc quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
+#define MSNAP_QSTAGE(QP, out, src, keep, mask)                                                                     \
+  asm("s_nop 1\n\ts_mov_b64 vcc, %16\n\t" MSNAP_QCND(0, 8, 17, QP) MSNAP_QCND(1, 9, 18, QP) MSNAP_QCND(2, 10, 19, QP) \
+          MSNAP_QCND(3, 11, 20, QP) MSNAP_QCND(4, 12, 21, QP) MSNAP_QCND(5, 13, 22, QP) MSNAP_QCND(6, 14, 23, QP)      \
+              MSNAP_QCND(7, 15, 24, QP)                                                                            \
+      : "=&v"(out[0]), "=&v"(out[1]), "=&v"(out[2]), "=&v"(out[3]), "=&v"(out[4]), "=&v"(out[5]), "=&v"(out[6]),    \
+        "=&v"(out[7])                                                                                              \
+      : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]), "v"(src[4]), "v"(src[5]), "v"(src[6]), "v"(src[7]),     \
+        "s"(mask), "v"(keep[0]), "v"(keep[1]), "v"(keep[2]), "v"(keep[3]), "v"(keep[4]), "v"(keep[5]), "v"(keep[6]), \
+        "v"(keep[7])                                                                                               \
+      : "vcc")
+// a, b: 4 doubles each as dwords (lo, hi); `bit` as a lane mask
+template <int STAGE>   // 1: partner = lane ^ 1, 2: partner = lane ^ 2
+__device__ __forceinline__ void quad_stage(uint32_t (&a)[8], uint32_t (&b)[8], unsigned long long bit) {
+  uint32_t na[8], nb[8];
+  const unsigned long long nbit = ~bit;
+  if constexpr (STAGE == 1) {
+    MSNAP_QSTAGE("[1,0,3,2]", nb, a, b, bit);
+    MSNAP_QSTAGE("[1,0,3,2]", na, b, a, nbit);
+  } else {
+    MSNAP_QSTAGE("[2,3,0,1]", nb, a, b, bit);
+    MSNAP_QSTAGE("[2,3,0,1]", na, b, a, nbit);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = na[k];
+    b[k] = nb[k];
   }
 }
+#undef MSNAP_QSTAGE
+#undef MSNAP_QCND
 
+// `blk` is this lane's drone-segment block (4 axes x 8 coefficients); all 64 lanes must be active
+// (the exchanges are quad-local and read their partners through DPP).
+__device__ __forceinline__ void store_quad8_at(double *__restrict__ blk, int a, const double (&c)[8], bool bad) {
+  double p[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) p[k] = c[k];
+  // a failed drone is rare: one wave-uniform test instead of 16 selects per segment
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+    asm volatile("" ::: "memory");   // keep the block a branch: the compiler would flatten it into selects again
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p[k] = bad ? __builtin_nan("") : p[k];
+  }
+  auto lo = [](double v) { return (uint32_t)__double2loint(v); };
+  auto hi = [](double v) { return (uint32_t)__double2hiint(v); };
+  // pieces P0..P3 = coefficient pairs (0,1) (2,3) (4,5) (6,7).  Stage 1 pairs (P0,P1) and (P2,P3):
+  uint32_t A[8] = {lo(p[0]), hi(p[0]), lo(p[1]), hi(p[1]), lo(p[4]), hi(p[4]), lo(p[5]), hi(p[5])};   // P0 | P2
+  uint32_t B[8] = {lo(p[2]), hi(p[2]), lo(p[3]), hi(p[3]), lo(p[6]), hi(p[6]), lo(p[7]), hi(p[7])};   // P1 | P3
+  quad_stage<1>(A, B, __builtin_amdgcn_ballot_w64((a & 1) != 0));
+  // stage 2 pairs (P0,P2) and (P1,P3)
+  uint32_t A2[8] = {A[0], A[1], A[2], A[3], B[0], B[1], B[2], B[3]};   // P0 | P1
+  uint32_t B2[8] = {A[4], A[5], A[6], A[7], B[4], B[5], B[6], B[7]};   // P2 | P3
+  quad_stage<2>(A2, B2, __builtin_amdgcn_ballot_w64((a & 2) != 0));
+  // now piece q = coefficient pair `a` of axis q
+  uint4 *o = reinterpret_cast<uint4 *>(blk + a * 2);
+  o[0] = make_uint4(A2[0], A2[1], A2[2], A2[3]);
+  o[4] = make_uint4(A2[4], A2[5], A2[6], A2[7]);
+  o[8] = make_uint4(B2[0], B2[1], B2[2], B2[3]);
+  o[12] = make_uint4(B2[4], B2[5], B2[6], B2[7]);
+}
+
+// The quads past the batch end replay the tile's last valid drone (same inputs, same instruction
+// stream, bitwise the same coefficients): they store on top of that drone's block instead of being
+// masked off.
 __device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_base, size_t drone_stride,
                                                     int nvalid, int lane, const double (&c)[8], bool bad) {
   const int dl = lane >> 2;
-  store_quad8_at(seg_base + (size_t)dl * drone_stride, dl < nvalid, lane & 3, c, bad);
+  store_quad8_at(seg_base + (size_t)(dl < nvalid ? dl : nvalid - 1) * drone_stride, lane & 3, c, bad);
 }
 
 // dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
@@ -540,10 +573,10 @@ __device__ __forceinline__ void stage_load_asm(const double *__restrict__ wp, co
   }
 }
 
-// retire the prefetch: all but the `younger` most recent vector-memory operations are complete
-template <int MAXM>
-__device__ __forceinline__ void stage_wait_asm(StageRegsAsm<MAXM> &r, int younger) {
-  wait_vmcnt_younger(younger);
+// retire the prefetch: all but the YOUNGER most recent vector-memory operations are complete
+template <int MAXM, int YOUNGER>
+__device__ __forceinline__ void stage_wait_asm(StageRegsAsm<MAXM> &r) {
+  wait_vmcnt<YOUNGER>();
   // tie the registers to this point so that no use is scheduled above the wait
 #pragma unroll
   for (int u = 0; u < StageRegsAsm<MAXM>::UW; ++u) asm volatile("" : "+v"(r.vw[u]));
@@ -629,7 +662,7 @@ solve_kernel(const double *__restrict__ wp, const double *__restrict__ tt, int s
       __syncthreads();
       store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
     }
-    // lanes past the end of the batch replay the last valid drone (stores are masked)
+    // lanes past the end of the batch replay the last valid drone (and store on top of its results)
     const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
     const double *lw = sWraw + dloc * wpitch + a;
     const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
@@ -786,14 +819,16 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
   StageRegsAsm<MAXM> pre;
   if ((int)blockIdx.x < ntiles)
     stage_load_asm(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane, pre);
+  wait_vmcnt<0>();   // the first tile's inputs (nothing to overlap them with)
   // Prefetch distance: the next tile's inputs are requested two segments before the end of the
   // backward sweep, when most of this tile's registers are dead.  (Requesting them right after the
   // forward sweep hides more latency on paper but measured 4 % slower at saturation)
-  // `stores_after_prefetch` is the exact number of younger store instructions the wait must leave
-  // in flight (tools/check_prefetch_isa.py counts them in the code object; the multi-tile tests of
-  // tests/test_solve_gpu.py compare a persistent wave's tiles with the same tiles solved alone).
+  // The wait at the top of a tile leaves the 2 x kStoresPerSeg stores of the two segments issued after the
+  // loads in flight (this kernel is launched for n_seg >= 2 only, so both always run and the immediate is a
+  // constant; waiting for the first of the two segments' stores as well costs 6 % at 65 536 x 10, order 9).
+  // tools/check_prefetch_isa.py counts the stores on every path of the code object; the multi-tile tests
+  // of tests/test_solve_gpu.py compare a persistent wave's tiles with the same tiles solved alone.
   constexpr int kStoresPerSeg = (NC == 8 ? 4 : NC / 2);
-  const int stores_after_prefetch = kStoresPerSeg * (M >= 2 ? 2 : 1);
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d_raw = tile * kDronesPerWave + dl;
@@ -802,8 +837,10 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
     const int nvalid = tile_valid(tile);
     const int next = tile + gridDim.x;
 
+    // tile top: a marker instruction for tools/check_prefetch_isa.py (priority 0 is the default: no effect)
+    asm volatile("s_setprio 0" ::: "memory");
     wave_lds_fence();   // the previous tile's LDS reads are done (in-order LDS, one wave)
-    stage_wait_asm(pre, tile == (int)blockIdx.x ? 0 : stores_after_prefetch);
+    stage_wait_asm<MAXM, 2 * kStoresPerSeg>(pre);
     stage_store_asm(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
     wave_lds_fence();
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
@@ -881,12 +918,14 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         const int nx = next < ntiles ? next : ntiles - 1;
         stage_load_asm(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
       }
-      if (i < M) {
+      if (i <= 1 || i < M) {   // n_seg >= 2 (launch_solve_k): segments 0 and 1 always exist
         double u[NU];
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
           double v = (i >= 1) ? zreg[i >= 1 ? i - 1 : 0][r] : 0.0;
-          if (i >= 1 && i < M - 1) {
+          if (i >= 1) {
+            // at the last knot (i == M - 1, the first iteration that runs) gq and un are still zero and
+            // the products add -0.0: bitwise z itself, without a select on the runtime segment count
 #pragma unroll
             for (int c = 0; c < NU; ++c) v = __builtin_fma(-gq[r][c], un[c], v);
           }
@@ -1255,7 +1294,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
-  if (M <= kRegMaxSeg2) {
+  if (M >= 2 && M <= kRegMaxSeg2) {   // (one segment: the rolled kernel below)
     const size_t nu = K - 1;
     const size_t in_bytes = solve_input_words(M) * sizeof(double);
     const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +

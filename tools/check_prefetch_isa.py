@@ -2,18 +2,18 @@
 """Build-time check of the hand-counted cross-tile prefetch of solve_kernel_reg (csrc/msnap_solve.hip).
 
 The persistent solve issues the next tile's input loads from inline asm during the last two
-segments of a tile and retires them with `s_waitcnt vmcnt(N)`, N = the store instructions issued
+segments of a tile and retires them with `s_waitcnt vmcnt(N)`, N <= the store instructions issued
 after them (the compiler does not see asm loads, so nothing else would wait for them, and a wait
 that is too loose would read registers whose loads have not landed).  This script disassembles the
 gfx950 code object inside msnap_solve.o and checks, for every solve_kernel_reg instance:
   1. the in-loop prefetch burst exists (UW dwordx4 + UT dwordx2 loads back to back);
   2. the kernel holds exactly MAXM x kStoresPerSeg coefficient stores (global_store_dwordx4: 4 per
-     segment at order 7, 5 at order 9) -- the compiler neither merged, split nor dropped one, so the
-     two segments that follow the prefetch in the source issue 2 x kStoresPerSeg of them -- and an
-     `s_waitcnt vmcnt(N)` with that N (launches with n_seg >= 2) and one with N / 2 (n_seg == 1);
-  3. where the code after the burst is laid out contiguously up to the end of the kernel (the order-7
-     instances), exactly 2 x kStoresPerSeg stores follow it and none of those instructions reads a
-     destination register of the burst.
+     segment at order 7, 5 at order 9): the compiler neither merged, split nor dropped one;
+  3. followed through the code object's branches (both outcomes, whatever the block layout): on EVERY
+     path from the burst to the tile-top marker (`s_setprio 0`, one per tile in front of the wait)
+     exactly 2 x kStoresPerSeg stores are issued (the kernel runs for n_seg >= 2 only) and no instruction
+     reads a destination register of the burst; on every path from the marker on, `s_waitcnt
+     vmcnt(2 x kStoresPerSeg)` comes before any store or any read of those registers.
 Exit status 1 (with a message) on a violation.   python3 tools/check_prefetch_isa.py [msnap_solve.o]
 """
 import os
@@ -51,8 +51,10 @@ def regs(tok):
 def check_kernel(name, body):
     k = int(re.search(r"ILi(\d+)ELi(\d+)E", name).group(1))          # K = 4 (order 7) or 5 (order 9)
     stores_per_seg = 4 if k == 4 else 5
-    ins = [ln.split(None, 1) for ln in body if ln and not ln.endswith(":")]
-    ins = [(p[0], p[1] if len(p) > 1 else "") for p in ins]
+    ins = []
+    for text, addr, target in body:
+        p = text.split(None, 1)
+        ins.append((p[0], p[1] if len(p) > 1 else "", addr, target))
     # prefetch bursts: maximal runs of global_load_dwordx4 / x2 with only address arithmetic between them
     bursts, i = [], 0
     while i < len(ins):
@@ -75,27 +77,87 @@ def check_kernel(name, body):
     for j in loads:
         dest |= regs(ins[j][1].split(",")[0])
     maxm = int(re.search(r"ILi(\d+)ELi(\d+)E", name).group(2))
-    total_stores = sum(1 for op, _ in ins if op == "global_store_dwordx4")
+    total_stores = sum(1 for op, _, _, _ in ins if op == "global_store_dwordx4")
     if total_stores != maxm * stores_per_seg:
         return f"{name}: {total_stores} coefficient stores in the kernel, expected {maxm} x {stores_per_seg}"
-    tail = ins[loads[-1] + 1:]
-    n_store = sum(1 for op, _ in tail if op == "global_store_dwordx4")
     want = 2 * stores_per_seg
-    contiguous = n_store == want          # otherwise the block layout interleaves earlier segments: skip check 3
-    waits = {int(m) for op, a in ins if op == "s_waitcnt" for m in re.findall(r"vmcnt\((\d+)\)", a)}
-    if want not in waits or stores_per_seg not in waits:
-        return f"{name}: no s_waitcnt vmcnt({want}) / vmcnt({stores_per_seg}) in the kernel (found {sorted(waits)})"
-    for op, a in (tail if contiguous else []):
-        if op.startswith("global_load_dwordx") or op in ("s_endpgm",):
-            continue
+    # control-flow walks (both branch outcomes, whatever the block layout):
+    #   A. from the end of the burst to the tile-top marker (`s_setprio 0`, issued once per tile in front of
+    #      the wait): the stores of the tile's last segments, no read of a burst register;
+    #   B. from the marker to the first vmcnt wait: every path holds one, nothing reads a burst register first.
+    index_of = {addr: k for k, (_, _, addr, _) in enumerate(ins)}
+    err = []
+
+    def reads_dest(op, a):
         ops = a.split(",")
         srcs = ",".join(ops[1:]) if op.startswith(("v_", "ds_read", "global_load")) else a
         if op.startswith(("global_store", "ds_write", "v_cmp", "v_cmpx", "s_")):
             srcs = a
-        hit = regs(srcs) & dest
-        if hit:
-            return f"{name}: `{op} {a}` reads prefetch register(s) v{sorted(hit)} before the wait"
-    return None if contiguous else ""
+        return regs(srcs) & dest
+
+    def make_walk(ends_at):
+        memo, on_stack = {}, set()
+
+        def walk(k):
+            """set of (stores issued, value of the terminating instruction) over the paths from instruction k"""
+            if k in memo:
+                return memo[k]
+            if k in on_stack or k >= len(ins):
+                return set()
+            on_stack.add(k)
+            out, stores, j = set(), 0, k
+            while j < len(ins):
+                op, a, _, target = ins[j]
+                end = ends_at(op, a)
+                if end is not None:
+                    out.add((stores, end))
+                    break
+                if op == "s_endpgm":
+                    break
+                if not op.startswith("global_load_dwordx"):
+                    hit = reads_dest(op, a)
+                    if hit:
+                        err.append(f"{name}: `{op} {a}` reads prefetch register(s) v{sorted(hit)} before the wait")
+                        break
+                if op.startswith("global_store"):
+                    stores += 1
+                if op == "s_branch" or op.startswith("s_cbranch"):
+                    if target not in index_of:
+                        err.append(f"{name}: target of `{op} {a}` not found")
+                        break
+                    nxt = [index_of[target]] + ([] if op == "s_branch" else [j + 1])
+                    for n in nxt:
+                        for st, w in walk(n):
+                            out.add((stores + st, w))
+                    break
+                j += 1
+            on_stack.discard(k)
+            memo[k] = out
+            return out
+        return walk
+
+    def at_marker(op, a):
+        return 0 if op == "s_setprio" else None
+
+    def at_vmcnt_wait(op, a):
+        m = re.findall(r"vmcnt\((\d+)\)", a) if op == "s_waitcnt" else []
+        return int(m[0]) if m else None
+
+    sys.setrecursionlimit(20000)
+    markers = [k for k, (op, _, _, _) in enumerate(ins) if op == "s_setprio"]
+    if len(markers) != 1:
+        return f"{name}: expected one tile-top marker (s_setprio), found {len(markers)}"
+    to_top = make_walk(at_marker)(loads[-1] + 1)
+    to_wait = make_walk(at_vmcnt_wait)(markers[0] + 1)
+    if err:
+        return err[0]
+    if not to_top or not to_wait:
+        return f"{name}: the tile top / its vmcnt wait is not reachable from the prefetch burst"
+    st_seen, w_seen = sorted({st for st, _ in to_top}), sorted({w for _, w in to_wait})
+    if st_seen != [want] or w_seen != [want] or {st for st, _ in to_wait} != {0}:
+        return (f"{name}: paths from the burst to the tile top issue {st_seen} stores (expected [{want}]); the waits "
+                f"behind the tile top are vmcnt{w_seen} (expected [{want}]) after {sorted({st for st, _ in to_wait})} stores")
+    return None
 
 
 def main():
@@ -112,7 +174,13 @@ def main():
             if not re.match(r"^[0-9a-f]+ <L\d+>:", ln):
                 cur = None
         elif cur is not None:
-            kernels[cur].append(ln.split("//")[0].strip())
+            text = ln.split("//")[0].strip()
+            m = re.search(r"//\s*([0-9A-Fa-f]+):", ln)
+            if not text or text.endswith(":") or not m:
+                continue
+            t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", ln)
+            base = kernels[cur][0][1] if kernels[cur] else int(m.group(1), 16)
+            kernels[cur].append((text, int(m.group(1), 16), base + int(t.group(1), 16) if t else None))
     if len(kernels) != 4:
         print(f"check_prefetch_isa: expected 4 solve_kernel_reg instances, found {len(kernels)}")
         return 1
@@ -121,9 +189,8 @@ def main():
     for e in bad:
         print("check_prefetch_isa:", e)
     if not bad:
-        full = sum(1 for e in res.values() if e is None)
-        print(f"check_prefetch_isa: {len(kernels)} solve_kernel_reg instances ok (store counts and waits; "
-              f"{full} of them also laid out contiguously: stores after the prefetch counted, no early reads)")
+        print(f"check_prefetch_isa: {len(kernels)} solve_kernel_reg instances ok (store counts, waits, and on every "
+              f"path from the prefetch to its wait: stores counted, no early reads)")
     return 1 if bad else 0
 
 
