@@ -124,13 +124,15 @@ def test_formation_collide_against_oracle(ctx7):
 
 @pytest.mark.parametrize("n,s,ro,r", [(70, 5, 0, 70), (200, 9, 0, 200), (333, 23, 0, 333), (333, 23, 100, 97),
                                       (333, 23, 0, 64), (333, 23, 269, 64), (500, 4, 130, 370), (97, 3, 0, 97),
-                                      (1000, 13, 0, 1000), (1000, 13, 640, 200), (129, 40, 0, 129)])
+                                      (1000, 13, 0, 1000), (1000, 13, 640, 200), (129, 40, 0, 129),
+                                      (128, 7, 0, 128), (257, 12, 0, 257), (260, 6, 128, 130), (135, 19, 3, 129)])
 def test_formation_collide_tiles(ctx7, n, s, ro, r):
-    """The tile kernel: pairs inside the rows' own column range are evaluated once and credited to
-    both drones (column-side minima through the register butterfly), everything else one-sidedly.
-    Row counts around the 64-row / 32-column block edges, shards at unaligned offsets, sample counts
-    around the 4-sample chunk, with exact ties between equidistant neighbours (lattice positions):
-    distances, partners (lowest index wins) and hits must equal the oracle's bit for bit."""
+    """The span kernel: pairs inside the rows' own column range are evaluated once and credited to
+    both drones (column-side minima through the per-wave LDS fold), everything else one-sidedly.
+    Row counts around the 128-row (two rows per lane) / 8-column block edges, shards at unaligned
+    offsets, sample counts around the 6-sample chunk, with exact ties between equidistant neighbours
+    (lattice positions): distances, partners (lowest index wins) and hits must equal the oracle's bit
+    for bit."""
     rng = np.random.default_rng(1000 * n + s)
     pos = rng.uniform(-3.0, 3.0, size=(n, s, 3))
     # a lattice part: many exactly equal distances, so partner choice is decided by the index rule
