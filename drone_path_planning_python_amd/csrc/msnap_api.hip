@@ -54,6 +54,7 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "twist_max_drones")) return &ctx->twist_max_drones;
   if (!strcmp(name, "no_twist")) return &ctx->no_twist;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
+  if (!strcmp(name, "own_stream_priority")) return &ctx->own_stream_priority;   // (read side; set has its own branch)
   return nullptr;
 }
 
@@ -158,6 +159,26 @@ int msnap_set_option(msnap_ctx *ctx, const char *name, long value) {
   if (!ctx || !name || value < 0 || value > (1L << 30)) return MSNAP_EINVAL;
   if (!strcmp(name, "pipe_chunk_mb")) {
     ctx->pipe_chunk_bytes = (size_t)(value > 0 ? value : 64) << 20;
+    return MSNAP_OK;
+  }
+  if (!strcmp(name, "own_stream_priority")) {
+    // 0 = default, 1 = the lowest priority the device offers, 2 = the highest: the context's own stream is
+    // re-created (work queued on it is drained first; an external stream set by msnap_set_stream stays)
+    if (value > 2) return MSNAP_EINVAL;
+    MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+    int least = 0, greatest = 0;
+    MSNAP_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t fresh = nullptr;
+    MSNAP_HIP(ctx, hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking,
+                                               value == 1 ? least : value == 2 ? greatest : 0));
+    const bool current = ctx->stream == ctx->own_stream;
+    if (ctx->own_stream) {
+      (void)hipStreamSynchronize(ctx->own_stream);
+      (void)hipStreamDestroy(ctx->own_stream);
+    }
+    ctx->own_stream = fresh;
+    if (current) ctx->stream = fresh;
+    ctx->own_stream_priority = (int)value;
     return MSNAP_OK;
   }
   if (!strcmp(name, "mesh_count_tests")) {

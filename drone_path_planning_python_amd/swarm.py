@@ -5,7 +5,9 @@ per rank.  The formation (drone-vs-drone) pass has one real exchange step: every
 rank samples its own shard, the sampled positions are all-gathered (RCCL over
 xGMI when the process group is "nccl"; "gloo" on CPU for the tests) and each
 rank then checks its own rows against all columns -- row-owned results, no
-reduction.  The mesh sweep replicates the (tiny) mesh and shards the drones.
+reduction.  The mesh sweep replicates the (tiny) mesh and shards the drones; it
+depends on the rank's own samples only, so with a second context (`side_ctx`) it
+runs on a side stream next to the exchange and the pairwise pass.
 
 torch / torch.distributed are plumbing here (device memory + the collective);
 all arithmetic happens in libmsnap through the `compute` object, by default a
@@ -34,14 +36,31 @@ def shard_sizes(n: int, world: int) -> list:
 
 
 class DeviceCompute:
-    """The three device operations of the formation pipeline, on torch CUDA tensors."""
+    """The device operations of the formation pipeline, on torch CUDA tensors.
 
-    def __init__(self, ctx, torch_module):
+    `side_ctx`: a second Context on the same device.  When given, `mesh_begin` launches the mesh sweep
+    on a side stream (ordered after what the main stream holds at that moment) and `mesh_end` makes the
+    main stream wait for it: the sweep overlaps the all-gather and the pairwise pass, whose launch ends
+    with SIMDs running out of shares."""
+
+    def __init__(self, ctx, torch_module, side_ctx=None):
         self.ctx = ctx
         self.torch = torch_module
         self.device = torch_module.device("cuda", ctx.device_id)
         # run on torch's current stream so the collective and the kernels order naturally
-        ctx.set_stream(torch_module.cuda.current_stream(self.device).cuda_stream)
+        self.main = torch_module.cuda.current_stream(self.device)
+        ctx.set_stream(self.main.cuda_stream)
+        self.side_ctx = side_ctx
+        self.side = None
+        if side_ctx is not None:
+            if side_ctx.device_id != ctx.device_id:
+                raise ValueError("side_ctx must live on the same device")
+            # the side context's own stream at the lowest priority: the sweep's workgroups are dispatched
+            # when the main stream's kernels have none waiting, i.e. into the end of the pairwise launch
+            side_ctx.set_option("own_stream_priority", 1)
+            side_ctx.use_own_stream()
+            self.side = torch_module.cuda.ExternalStream(side_ctx.stream(), device=self.device)
+        self._mesh_pending = None
 
     def solve(self, wp, t):
         torch = self.torch
@@ -73,14 +92,45 @@ class DeviceCompute:
                                               pos_all, radius, md, partner, hit)
         return md, partner, hit
 
-    def mesh(self, pos, tris, radius):
+    def _mesh_on(self, ctx, pos, tris, radius, md=None, hit=None):
         torch = self.torch
         n = pos.shape[0]
-        md = torch.empty((n,), dtype=torch.float64, device=self.device)
-        hit = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if md is None:
+            md = torch.empty((n,), dtype=torch.float64, device=self.device)
+            hit = torch.empty((n,), dtype=torch.int32, device=self.device)
         if n:
-            self.ctx.mesh_sweep_device(n, pos.shape[1], pos, tris.shape[0], tris, radius, md, hit)
+            ctx.mesh_sweep_device(n, pos.shape[1], pos, tris.shape[0], tris, radius, md, hit)
         return md, hit
+
+    def mesh(self, pos, tris, radius):
+        return self._mesh_on(self.ctx, pos, tris, radius)
+
+    def mesh_begin(self, pos, tris, radius):
+        """Start the mesh sweep; with a side context it runs next to whatever the main stream does until
+        `mesh_end`, otherwise it is an ordinary launch on the main stream.
+
+        All buffers are main-stream allocations: the side stream starts after everything the main stream
+        holds now (so a recycled output block is quiet), the inputs are kept referenced until `mesh_end`,
+        and `mesh_end` orders the main stream behind the sweep before anything can be recycled."""
+        if self._mesh_pending is not None:
+            raise RuntimeError("mesh_begin: a sweep is already pending")
+        if self.side is None:
+            self._mesh_pending = (self.mesh(pos, tris, radius), None)
+            return
+        n = pos.shape[0]
+        md = self.torch.empty((n,), dtype=self.torch.float64, device=self.device)
+        hit = self.torch.empty((n,), dtype=self.torch.int32, device=self.device)
+        self.side.wait_stream(self.main)            # the samples (and the mesh) are ready
+        self._mesh_pending = (self._mesh_on(self.side_ctx, pos, tris, radius, md, hit), (pos, tris))
+
+    def mesh_end(self):
+        """(min_dist, hit) of the pending sweep, ordered into the main stream."""
+        if self._mesh_pending is None:
+            raise RuntimeError("mesh_end without mesh_begin")
+        (out, _keep), self._mesh_pending = self._mesh_pending, None
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        return out
 
 
 @dataclass
@@ -91,6 +141,8 @@ class FormationResult:
     partner: object      # [hi-lo] global index
     hit: object          # [hi-lo]
     positions_all: object  # [N, S, 3] after the all-gather
+    mesh_min_dist: object = None   # [hi-lo] when a mesh was given
+    mesh_hit: object = None
 
 
 def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, torch):
@@ -118,8 +170,11 @@ def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, t
 
 
 def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, rank: int, dt: float,
-                   n_samples: int, radius: float, dist=None, torch=None, status_local=None) -> FormationResult:
-    """Sample the local shard, exchange, collide own rows against everybody.
+                   n_samples: int, radius: float, dist=None, torch=None, status_local=None,
+                   mesh_tris=None) -> FormationResult:
+    """Sample the local shard, exchange, collide own rows against everybody; with `mesh_tris`
+    ([T, 3, 3]) also sweep the local shard against the mesh, started right behind the sampler so
+    that a compute object with a side stream overlaps it with the exchange and the pairwise pass.
 
     `status_local` (the solve's per-drone status of this shard): a failed solve leaves NaN
     coefficients, and NaN samples never win a minimum (include/msnap.h) -- such a drone would
@@ -129,9 +184,17 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
         raise ValueError("formation_pass: the solve reported failed drones (status != 0) in rows "
                          f"[{lo}, {hi}); their samples are NaN and cannot be collision-checked")
     pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
+    overlapped = mesh_tris is not None and hasattr(compute, "mesh_begin")
+    if overlapped:
+        compute.mesh_begin(pos_local, mesh_tris, radius)
     pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch) if world > 1 else pos_local
     md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)
-    return FormationResult(lo, hi, md, partner, hit, pos_all)
+    mmd = mhit = None
+    if overlapped:
+        mmd, mhit = compute.mesh_end()
+    elif mesh_tris is not None:
+        mmd, mhit = compute.mesh(pos_local, mesh_tris, radius)
+    return FormationResult(lo, hi, md, partner, hit, pos_all, mmd, mhit)
 
 
 def default_sample_count(total_duration: float, dt: float) -> int:

@@ -75,8 +75,9 @@ int msnap_sync(msnap_ctx *ctx);
  * pinned ones let the copy engines read and write them directly). */
 int msnap_host_alloc(void **ptr, size_t bytes);
 int msnap_host_free(void *ptr);
-/* Launch-geometry options of a context (tests and tuning tools; every default is chosen per
- * launch from the device's CU count).  Unknown names return MSNAP_EINVAL.
+/* Options of a context (launch geometry: tests and tuning tools, every default is chosen per
+ * launch from the device's CU count; stream priority: callers that overlap two contexts).  Unknown
+ * names return MSNAP_EINVAL.
  *   "solve_grid_waves"     cap on the persistent grid of the large-batch solve kernel (0 = default);
  *                          a small cap makes every wave walk several tiles (the regime of a
  *                          saturating batch) on a batch the oracle checks in seconds
@@ -88,6 +89,11 @@ int msnap_host_free(void *ptr);
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
  *   "pipe_chunk_mb"        output megabytes per chunk of the chunked host-pointer solves
+ *   "own_stream_priority"  0 default, 1 the lowest, 2 the highest priority the device offers: re-creates
+ *                          the context's own stream (after draining it).  A pass that should only fill the
+ *                          gaps of another context's work -- the mesh sweep beside the pairwise pass --
+ *                          runs on a lowest-priority stream: its workgroups are dispatched when the
+ *                          other queue has none waiting
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
  * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_COLLIDE_WAVES_PER_CU and
  * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */

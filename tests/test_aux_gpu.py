@@ -380,6 +380,38 @@ def test_flatness_evaluator_batch_on_solved_swarm(ctx7):
             np.testing.assert_allclose(out[d, s], ref, rtol=1e-10, atol=1e-10)
 
 
+def test_formation_pass_mesh_on_side_stream(ctx7):
+    """formation_pass with a mesh: the sweep runs on the side context's stream beside the pairwise pass and
+    must equal the sweep launched in stream order (and the pairwise results must not notice it)."""
+    import torch
+    from drone_path_planning_python_amd import Context, stl, swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(43, 300, 6)
+    wp[..., :3] *= 0.4
+    tris = torch.from_numpy(np.ascontiguousarray(stl.box_mesh((-1, -1, -1), (0.5, 0.2, 0.3)))).cuda()
+    side = Context(ctx7.device_id, 7, 16)
+    try:
+        twp, tt = torch.from_numpy(wp).cuda(), torch.from_numpy(t).cuda()
+        plain = sw.DeviceCompute(ctx7, torch)
+        coef, dur, status = plain.solve(twp, tt)
+        S = 45
+        ref = sw.formation_pass(plain, coef, dur, 300, 1, 0, 0.1, S, 0.2, torch=torch, mesh_tris=tris)
+        both = sw.DeviceCompute(ctx7, torch, side_ctx=side)
+        for _ in range(3):      # repeated: the side stream's ordering against the main stream's reuse of buffers
+            res = sw.formation_pass(both, coef, dur, 300, 1, 0, 0.1, S, 0.2, torch=torch, mesh_tris=tris)
+            torch.cuda.synchronize()
+            for a, b in ((res.mesh_min_dist, ref.mesh_min_dist), (res.mesh_hit, ref.mesh_hit), (res.min_dist, ref.min_dist),
+                         (res.partner, ref.partner), (res.hit, ref.hit)):
+                np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+        assert ref.mesh_hit.any().item() and not ref.mesh_hit.all().item()
+        with pytest.raises(RuntimeError):
+            both.mesh_end()
+    finally:
+        torch.cuda.synchronize()
+        ctx7.use_own_stream()
+        side.close()
+
+
 def test_device_formation_pass_single_rank(ctx7):
     """swarm.DeviceCompute end to end on device tensors (world = 1: no collective),
     against the host-pointer entry points."""
