@@ -59,7 +59,8 @@ HBM_COPY_GBS = 6290.0
 # fp64 vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz (= 78.6 TFLOP/s of FMA / 2)
 VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
-PAIR_OPS = 9                   # 3 differences, 3 products, 2 sums, 1 minimum per pair and sample
+PAIR_OPS = 7                   # vector instructions per pair and sample: 3 differences, 1 product, 2 FMAs, 1 minimum
+PAIR_FLOPS = 9                 # the same as floating-point operations (an FMA counts two)
 
 
 def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
@@ -486,7 +487,11 @@ def run_formation_config(cfg, env, reps, warm):
             "pairwise": {"kernel": "msnap::collide_span_kernel + collide_merge_kernel", "bound": "valu_f64",
                          "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
-                         "note": "frac counts each unordered pair once (N(N-1)/2 x S x 9 operations, SURVEY.md 8d), "
+                         "tflops": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
+                         "note": "frac counts each unordered pair once (N(N-1)/2 x S x 7 vector instructions: 3 "
+                                 "differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md 8d) against "
+                                 "the fp64 issue peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); tflops counts the same "
+                                 "work as 9 flops per pair-sample (peak 78.6 with nothing but FMAs), "
                                  "per GPU; frac_executed counts the pair-samples the kernel evaluates"},
         },
     }

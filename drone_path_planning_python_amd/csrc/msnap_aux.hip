@@ -495,7 +495,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // operations per pair and sample (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the
 // NumPy oracle, which decides ties between equidistant formation neighbours -- and the minimum).
 // The running minima of a block of 8 columns stay in registers over all samples.  A scalar load has
-// only an all-or-nothing wait, so a wave has ONE column fetch (6 samples, 2 x 54 operations) in
+// only an all-or-nothing wait, so a wave has ONE column fetch (6 samples, 2 x 42 operations) in
 // flight while it computes the previous one; the other waves of the SIMD (4 fit) cover the rest of
 // the latency.  The rows are read from a transposed image [sample][xyz][row] written once per call
 // (coalesced 512-byte loads; drone-major row loads would saturate the texture addresser).
@@ -635,12 +635,12 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       for (int q = 0; q < CH; ++q) {
         const double dx0 = k.minus(3 * q + 0, ax[q]), dy0 = k.minus(3 * q + 1, ay[q]), dz0 = k.minus(3 * q + 2, az[q]);
         const double dx1 = k.minus(3 * q + 0, bx[q]), dy1 = k.minus(3 * q + 1, by[q]), dz1 = k.minus(3 * q + 2, bz[q]);
-        m0 = __builtin_fmin(dx0 * dx0 + dy0 * dy0 + dz0 * dz0, m0);
-        m1 = __builtin_fmin(dx1 * dx1 + dy1 * dy1 + dz1 * dz1, m1);
+        m0 = __builtin_fmin(__builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0)), m0);
+        m1 = __builtin_fmin(__builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1)), m1);
       }
     };
     // two register sets alternate: the loads of column j+1 are issued right after the wait for
-    // column j and fly during its 2 x 6 x 9 VALU operations
+    // column j and fly during its 2 x 6 x 7 VALU operations
     ColChunk ca, cb2;
     ca.fetch(pc);
 #pragma unroll
@@ -822,7 +822,7 @@ collide_short_kernel(const double *__restrict__ prow, const double *__restrict__
       const double dx = pc[(size_t)sq * 3 + 0] - pr[(size_t)sq * 3 + 0];
       const double dy = pc[(size_t)sq * 3 + 1] - pr[(size_t)sq * 3 + 1];
       const double dz = pc[(size_t)sq * 3 + 2] - pr[(size_t)sq * 3 + 2];
-      const double d2 = dx * dx + dy * dy + dz * dz;
+      const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
       m = __builtin_fmin(d2, m);
     }
     if (j == grow) m = INFINITY;

@@ -226,7 +226,9 @@ void msnap_oracle_sample(int n_drones, int n_seg, int ncoef, const double *coef,
 }
 
 /* pos [N][S][3]: min over other drones j and samples of |p_i - p_j|; partner = lowest j attaining it;
- * hit = min_dist < 2 r.  NaN samples never win a minimum (include/msnap.h). */
+ * hit = min_dist < 2 r.  Squared distance as include/msnap.h defines it: fma(dz, dz, fma(dy, dy, dx*dx))
+ * (libm's fma is correctly rounded whether or not the host has the instruction).  NaN samples never win a
+ * minimum. */
 void msnap_oracle_formation_collide(int n, int n_samples, const double *pos, double radius, int n_threads,
                                     double *min_dist, int *partner, int *hit) {
 #ifdef _OPENMP
@@ -247,7 +249,7 @@ void msnap_oracle_formation_collide(int n, int n_samples, const double *pos, dou
         const double dx = pj[3 * s + 0] - pi[3 * s + 0];
         const double dy = pj[3 * s + 1] - pi[3 * s + 1];
         const double dz = pj[3 * s + 2] - pi[3 * s + 2];
-        const double d2 = dx * dx + dy * dy + dz * dz;
+        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
         if (d2 < m) m = d2;
       }
       if (m < best) { best = m; bj = j; }

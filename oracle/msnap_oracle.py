@@ -447,18 +447,54 @@ def snap_cost(coef: np.ndarray, dur: np.ndarray) -> np.ndarray:
 # UNPINNED.  Semantics defined by this repo:
 # drones are spheres of radius r sampled every dt with a5 semantics.
 # --------------------------------------------------------------------------
+def _two_sum(a, b):
+    """a + b = s + e exactly (Knuth)."""
+    s = a + b
+    bb = s - a
+    return s, (a - (s - bb)) + (b - bb)
+
+
+def fma_square(y: np.ndarray, c: np.ndarray) -> np.ndarray:
+    """fma(y, y, c) = y*y + c with ONE rounding, vectorised in plain float64 arithmetic.
+
+    y*y = p + e exactly (Dekker's product with Veltkamp splitting); c + p + e is then accumulated with
+    error-free sums, so that the last addition rounds the exact value once.  The one configuration a final
+    floating-point addition gets wrong -- the leading part lands exactly half way between two doubles and
+    a lower-order term breaks the tie -- is detected and fixed.  Valid while nothing overflows or
+    underflows (positions are metres)."""
+    y = np.asarray(y, dtype=np.float64)
+    c = np.asarray(c, dtype=np.float64)
+    t = 134217729.0 * y                  # 2^27 + 1
+    h = t - (t - y)
+    lo = y - h
+    p = y * y
+    e = ((h * h - p) + 2.0 * (h * lo)) + lo * lo
+    s1, t1 = _two_sum(c, p)
+    s2, t2 = _two_sum(t1, e)             # exact value = s1 + s2 + t2
+    r, u = _two_sum(s1, s2)              # r = fl(s1 + s2), exact value = r + u + t2
+    out = r + (u + t2)
+    # u exactly half an ulp of r (r + 2u is the neighbouring double) and t2 on the same side: the exact value
+    # is beyond the half-way point, but fl(u + t2) == u ties back to r
+    step = (r + 2.0 * u) - r
+    tie = (u != 0.0) & (step == 2.0 * u) & (t2 != 0.0) & (np.sign(t2) == np.sign(u)) & ((u + t2) == u)
+    out = np.where(tie, r + 2.0 * u, out)
+    bad = ~(np.isfinite(y) & np.isfinite(c))
+    return np.where(bad, y * y + c, out)
+
+
 def formation_collide(pos: np.ndarray, radius: float):
     """pos [N,S,3] -> (min_dist [N] over other drones and samples, partner [N],
     hit [N] bool: min_dist < 2r).  partner = lowest index attaining the min.
-    Squared distances are (dx*dx + dy*dy) + dz*dz, each operation rounded separately;
-    NaN samples never win a minimum (include/msnap.h)."""
+    Squared distances are fma(dz, dz, fma(dy, dy, dx*dx)) (include/msnap.h: the differences and dx*dx
+    rounded once each, then two fused multiply-adds -- `fma_square` restates them exactly);
+    NaN samples never win a minimum."""
     N = pos.shape[0]
     mind = np.full(N, np.inf)
     partner = np.full(N, -1, dtype=np.int32)
     for i in range(N):
         d = pos - pos[i][None, :, :]
-        sq = d * d
-        d2 = np.fmin.reduce((sq[..., 0] + sq[..., 1]) + sq[..., 2], axis=1)
+        dx2 = d[..., 0] * d[..., 0]
+        d2 = np.fmin.reduce(fma_square(d[..., 2], fma_square(d[..., 1], dx2)), axis=1)
         d2 = np.where(np.isnan(d2), np.inf, d2)
         d2[i] = np.inf
         j = int(np.argmin(d2))

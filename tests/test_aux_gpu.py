@@ -156,8 +156,7 @@ def test_formation_collide_rows_not_among_columns(ctx7):
     np.testing.assert_array_equal(partner[:20], ref[1][100:120])
     for q in range(20, 50):                                    # rows 120..149 meet every column
         d = pos[:120] - pos[100 + q][None]
-        sq = d * d
-        d2 = ((sq[..., 0] + sq[..., 1]) + sq[..., 2]).min(axis=1)
+        d2 = O.fma_square(d[..., 2], O.fma_square(d[..., 1], d[..., 0] * d[..., 0])).min(axis=1)
         assert md[q] == np.sqrt(d2.min()) and partner[q] == int(np.argmin(d2))
 
 
