@@ -215,3 +215,33 @@ def test_nav_path_quaternion_and_arrays():
     np.testing.assert_array_equal(dur[0], mat[:, 0])
     ref = O.nav_path_poses(mat, 0.5)
     assert ref.shape == (len(np.arange(0, tr.duration, 0.5)), 7)
+
+
+def test_fma_square_is_exactly_rounded():
+    """The NumPy oracle's fused multiply-add (the pairwise pass's squared distance, include/msnap.h)
+    against rational arithmetic: random metres, values whose sum lands half way between two doubles with
+    a lower-order term breaking the tie, cancellation, and the C oracle's fma() on a whole swarm."""
+    import c_oracle
+    from fractions import Fraction
+    rng = np.random.default_rng(12)
+    y = rng.uniform(-50, 50, 3000)
+    c = rng.uniform(0, 5000, 3000)
+    c[:1000] *= 1e-6
+    c[1000:1500] *= 1e6
+    got = O.fma_square(y, c)
+    assert all(float(Fraction(a) * Fraction(a) + Fraction(b)) == g for a, b, g in zip(y, c, got))
+    # integers: y*y needs up to 60 bits, c a few units in the last place around the half-way points
+    y = rng.integers(1 << 26, 1 << 30, size=3000).astype(np.float64)
+    ce = rng.integers(50, 58, size=3000)
+    c = (np.ldexp(rng.integers(1 << 20, 1 << 21, size=3000).astype(np.float64), ce - 20)
+         + rng.integers(-3, 4, size=3000) * np.ldexp(1.0, ce - 53))
+    got = O.fma_square(y, c)
+    assert all(float(Fraction(int(a)) ** 2 + Fraction(b)) == g for a, b, g in zip(y, c, got))
+    y = rng.uniform(1, 2, 3000)
+    c = -(y * y) * (1 + rng.integers(-4, 5, size=3000) * 2.0 ** -52)
+    got = O.fma_square(y, c)
+    assert all(float(Fraction(a) * Fraction(a) + Fraction(b)) == g for a, b, g in zip(y, c, got))
+    pos = rng.uniform(-3, 3, size=(90, 11, 3))
+    pos[:30] = np.round(pos[:30] * 2) / 2
+    for a, b in zip(O.formation_collide(pos, 0.3), c_oracle.formation_collide(pos, 0.3)):
+        np.testing.assert_array_equal(a, b)
