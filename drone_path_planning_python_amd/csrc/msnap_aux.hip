@@ -635,8 +635,13 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       for (int q = 0; q < CH; ++q) {
         const double dx0 = k.minus(3 * q + 0, ax[q]), dy0 = k.minus(3 * q + 1, ay[q]), dz0 = k.minus(3 * q + 2, az[q]);
         const double dx1 = k.minus(3 * q + 0, bx[q]), dy1 = k.minus(3 * q + 1, by[q]), dz1 = k.minus(3 * q + 2, bz[q]);
-        m0 = __builtin_fmin(__builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0)), m0);
-        m1 = __builtin_fmin(__builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1)), m1);
+        // the minimum by hand: behind the wait's register tie the compiler no longer knows the accumulator to
+        // be canonical and would put a v_max in front of every fmin.  Neither operand can be a signalling NaN
+        // (d2 comes out of arithmetic, m out of earlier minima), and a quiet NaN loses, as fmin's would.
+        const double d20 = __builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0));
+        const double d21 = __builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1));
+        asm("v_min_f64 %0, %1, %0" : "+v"(m0) : "v"(d20));
+        asm("v_min_f64 %0, %1, %0" : "+v"(m1) : "v"(d21));
       }
     };
     // two register sets alternate: the loads of column j+1 are issued right after the wait for
