@@ -604,10 +604,13 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
   double acc0[NC], acc1[NC];
 #pragma unroll
   for (int jj = 0; jj < NC; ++jj) acc0[jj] = acc1[jj] = INFINITY;
-  for (int sc = 0; sc < S; sc += CH) {
-    // a short last chunk is moved back to overlap its predecessor (a minimum does not mind
-    // seeing a sample twice), so every chunk takes the wide scalar loads
-    const int s0 = (S - sc < CH) ? S - CH : sc;
+  // One or two samples behind the last whole chunk (91 = 15 x 6 + 1) go through a plain loop at the end;
+  // a longer remainder is a last chunk moved back to overlap its predecessor (a minimum does not mind seeing
+  // a sample twice), so that every chunk takes the wide scalar loads.
+  const int rem = S % CH;
+  const int Sw = (rem == 1 || rem == 2) ? S - rem : S;
+  for (int sc = 0; sc < Sw; sc += CH) {
+    const int s0 = (Sw - sc < CH) ? Sw - CH : sc;
     double ax[CH], ay[CH], az[CH], bx[CH], by[CH], bz[CH];
     // the rows come from the transposed image [sample][xyz][row]: the 64 lanes of a load read 512
     // contiguous bytes (from the drone-major layout every lane would touch its own cache line, and with two
@@ -658,6 +661,20 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       cb2.wait(acc1[jj]);
       if (jj + 2 < NC) ca.fetch(pc);
       consume(acc0[jj + 1], acc1[jj + 1], cb2);
+    }
+  }
+  for (int s1 = Sw; s1 < S; ++s1) {
+    const double *pt = prowT + (size_t)s1 * 3 * g.Rp;
+    const double *px = pt, *py = pt + g.Rp, *pz = pt + 2 * (size_t)g.Rp;
+    const double ax = px[lane], ay = py[lane], az = pz[lane];
+    const double bx = px[lane + kWave], by = py[lane + kWave], bz = pz[lane + kWave];
+#pragma unroll
+    for (int jj = 0; jj < NC; ++jj) {
+      const double *pc = pcol + ((size_t)(cj + (jj < ncols ? jj : ncols - 1)) * S + s1) * 3;
+      const double cx = pc[0], cy = pc[1], cz = pc[2];
+      const double dx0 = cx - ax, dy0 = cy - ay, dz0 = cz - az, dx1 = cx - bx, dy1 = cy - by, dz1 = cz - bz;
+      acc0[jj] = __builtin_fmin(__builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0)), acc0[jj]);
+      acc1[jj] = __builtin_fmin(__builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1)), acc1[jj]);
     }
   }
   // row side: columns ascend, so the lowest index wins a tie

@@ -125,7 +125,8 @@ def test_formation_collide_against_oracle(ctx7):
 @pytest.mark.parametrize("n,s,ro,r", [(70, 5, 0, 70), (200, 9, 0, 200), (333, 23, 0, 333), (333, 23, 100, 97),
                                       (333, 23, 0, 64), (333, 23, 269, 64), (500, 4, 130, 370), (97, 3, 0, 97),
                                       (1000, 13, 0, 1000), (1000, 13, 640, 200), (129, 40, 0, 129),
-                                      (128, 7, 0, 128), (257, 12, 0, 257), (260, 6, 128, 130), (135, 19, 3, 129)])
+                                      (128, 7, 0, 128), (257, 12, 0, 257), (260, 6, 128, 130), (135, 19, 3, 129),
+                                      (200, 8, 0, 200), (140, 14, 5, 130), (150, 20, 0, 150)])
 def test_formation_collide_tiles(ctx7, n, s, ro, r):
     """The span kernel: pairs inside the rows' own column range are evaluated once and credited to
     both drones (column-side minima through the per-wave LDS fold), everything else one-sidedly.
