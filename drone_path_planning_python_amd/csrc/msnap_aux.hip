@@ -859,18 +859,22 @@ collide_short_kernel(const double *__restrict__ prow, const double *__restrict__
   hit[r] = (dist < 2.0 * radius) ? 1 : 0;
 }
 
-// One workgroup per 64 rows, kMergeParts sub-groups of 64 lanes: sub-group q sweeps every kMergeParts-th
-// partial entry of its rows (a drone has a few hundred of them: swept by one thread the kernel is 28 us of
-// dependent loads at 4096 drones), the sub-groups' candidates are folded through LDS.
+// One workgroup per kMergeRows rows, kMergeParts sub-groups: sub-group q sweeps every kMergeParts-th partial
+// entry of its rows (a drone has a few hundred of them: swept by one thread the kernel is 28 us of dependent
+// loads at 4096 drones; with 64 rows per workgroup only 64 of the 256 CUs had work), the sub-groups'
+// candidates are folded through LDS.  16 consecutive rows are 128 contiguous bytes of a partial entry.
+// (64 sub-groups with 8 loads per round: 12 us instead of 9 -- the sequential fold and the big workgroups cost
+// more than the shorter sweeps save.)
+constexpr int kMergeRows = 16;
 constexpr int kMergeParts = 16;
-__global__ void __launch_bounds__(kWave * kMergeParts)
+__global__ void __launch_bounds__(kMergeRows * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
                      double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
-  __shared__ double sD[kMergeParts][kWave];
-  __shared__ int sJ[kMergeParts][kWave];
-  const int lane = threadIdx.x & (kWave - 1), q = threadIdx.x / kWave;
-  const int r_raw = blockIdx.x * kWave + lane;
+  __shared__ double sD[kMergeParts][kMergeRows];
+  __shared__ int sJ[kMergeParts][kMergeRows];
+  const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
+  const int r_raw = blockIdx.x * kMergeRows + lr;
   const int r = r_raw < g.R ? r_raw : g.R - 1;
   double best = INFINITY;
   int bj = -1;
@@ -904,14 +908,14 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
     // column side: the row blocks before this drone's own
     if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I);
   }
-  sD[q][lane] = best;
-  sJ[q][lane] = bj;
+  sD[q][lr] = best;
+  sJ[q][lr] = bj;
   __syncthreads();
   if (q == 0 && r_raw < g.R) {
 #pragma unroll
     for (int k = 1; k < kMergeParts; ++k) {
-      const double v = sD[k][lane];
-      const int j = sJ[k][lane];
+      const double v = sD[k][lr];
+      const int j = sJ[k][lr];
       if (j >= 0 && (v < best || (v == best && j < bj))) {
         best = v;
         bj = j;
@@ -941,7 +945,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.upw = g.upw_tail = 1;
     g.split = 0;
     g.total = 0;
-    hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0, ctx->stream,
+    hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
                        (const int32_t *)nullptr, radius, min_dist, partner, hit);
     MSNAP_HIP(ctx, hipGetLastError());
@@ -1005,7 +1009,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream,
                      (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave * kMergeParts), 0,
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
