@@ -681,6 +681,22 @@ def test_options_api(ctx7):
     for name in ("solve_grid_waves", "gemm_grid_waves", "twist_max_drones", "no_twist", "collide_waves_per_cu"):
         assert ctx7.get_option(name) == 0
     assert ctx7.get_option("pipe_chunk_mb") == 64
+    # the context's own stream at another priority: re-created, still the current one, still solves
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(3, 40, 5)
+    c = Context(ctx7.device_id, 7, 16)
+    try:
+        ref = c.solve_batch(wp, t)[0]
+        for prio in (1, 2, 0):
+            before = c.stream()
+            c.set_option("own_stream_priority", prio)
+            assert c.get_option("own_stream_priority") == prio and c.stream() != 0
+            np.testing.assert_array_equal(c.solve_batch(wp, t)[0], ref)
+        with pytest.raises(MsnapError):
+            c.set_option("own_stream_priority", 3)
+    finally:
+        c.close()
 
 
 def test_two_threads_two_contexts_and_one_shared_context(golden):
