@@ -689,7 +689,6 @@ def test_options_api(ctx7):
     try:
         ref = c.solve_batch(wp, t)[0]
         for prio in (1, 2, 0):
-            before = c.stream()
             c.set_option("own_stream_priority", prio)
             assert c.get_option("own_stream_priority") == prio and c.stream() != 0
             np.testing.assert_array_equal(c.solve_batch(wp, t)[0], ref)
