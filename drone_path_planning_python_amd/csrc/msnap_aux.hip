@@ -512,7 +512,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // minimum over a drone's row-side shares and column-side row blocks (lowest partner index wins
 // ties on both sides).
 // ------------------------------------------------------------------------------------
-constexpr int kRowsPerLane = 2;
+constexpr int kRowsPerLane = 2;   // (3 rows x 4-column blocks, 165 VGPRs, 3 waves per SIMD: 4096 x 91 in 346 us against 230)
 constexpr int kRowBlock = kWave * kRowsPerLane;
 constexpr int kColBlock = 8;      // column drones whose running minima a lane keeps in registers (per row)
 constexpr int kSampleChunk = 6;   // samples per scalar fetch
@@ -585,25 +585,33 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   return __hiloint2double(hi, lo);
 }
 
-// One block of NC (a multiple of 4, <= kColBlock) consecutive columns [cj, cj + ncols) against the
-// wave's 128 rows: straight-line code over the columns -- with a branch inside the column loop the
+// What a lane carries through a share: its kRowsPerLane rows (lane, lane + 64, ...)
+struct RowSet {
+  bool live[kRowsPerLane];       // row exists (rows past the batch end replay row R - 1 and must not win)
+  int grow[kRowsPerLane];        // global index (to exclude the drone itself)
+  double best[kRowsPerLane];     // row-side minimum over the share's columns
+  int bestj[kRowsPerLane];
+};
+
+// One block of NC (even, <= kColBlock) consecutive columns [cj, cj + ncols) against the wave's
+// kRowBlock rows: straight-line code over the columns -- with a branch inside the column loop the
 // scalar register sets cross basic blocks and the compiler copies every fetched value into vector
 // registers (36 extra VALU moves per fetch) -- so a short block takes the next instance up and
 // re-reads its last column instead of branching.
 template <int NC>
 __device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ prowT,
-                                              const double *__restrict__ pcol, int cj,
-                                              int ncols, bool two_sided, bool live0, bool live1, int grow0, int grow1,
-                                              int I, int lane, double *sFold, int *sFoldI, double &best0, int &bestj0,
-                                              double &best1, int &bestj1, double *__restrict__ cpart_d2,
-                                              int32_t *__restrict__ cpart_i) {
+                                              const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
+                                              RowSet &rs, int I, int lane, double *sFold, int *sFoldI,
+                                              double *__restrict__ cpart_d2, int32_t *__restrict__ cpart_i) {
 #pragma clang fp contract(off)
-  constexpr int CH = kSampleChunk;
+  constexpr int CH = kSampleChunk, RPL = kRowsPerLane;
   const int S = g.S;
   const int stride = S * 3;
-  double acc0[NC], acc1[NC];
+  double acc[RPL][NC];
 #pragma unroll
-  for (int jj = 0; jj < NC; ++jj) acc0[jj] = acc1[jj] = INFINITY;
+  for (int rr = 0; rr < RPL; ++rr)
+#pragma unroll
+    for (int jj = 0; jj < NC; ++jj) acc[rr][jj] = INFINITY;
   // One or two samples behind the last whole chunk (91 = 15 x 6 + 1) go through a plain loop at the end;
   // a longer remainder is a last chunk moved back to overlap its predecessor (a minimum does not mind seeing
   // a sample twice), so that every chunk takes the wide scalar loads.
@@ -611,110 +619,122 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
   const int Sw = (rem == 1 || rem == 2) ? S - rem : S;
   for (int sc = 0; sc < Sw; sc += CH) {
     const int s0 = (Sw - sc < CH) ? Sw - CH : sc;
-    double ax[CH], ay[CH], az[CH], bx[CH], by[CH], bz[CH];
+    double row[RPL][CH][3];
     // the rows come from the transposed image [sample][xyz][row]: the 64 lanes of a load read 512
-    // contiguous bytes (from the drone-major layout every lane would touch its own cache line, and with two
-    // rows per lane the texture addresser, not the VALU, would set the pace: TA_BUSY 79 %)
+    // contiguous bytes (from the drone-major layout every lane would touch its own cache line, and with
+    // several rows per lane the texture addresser, not the VALU, would set the pace: TA_BUSY 79 %)
     // (uniform base per load, lane offset in one register: no per-lane 64-bit address arithmetic)
     const double *pt = prowT + (size_t)s0 * 3 * g.Rp;
 #pragma unroll
-    for (int q = 0; q < CH; ++q) {
-      const double *px = pt + (size_t)(3 * q + 0) * g.Rp, *py = pt + (size_t)(3 * q + 1) * g.Rp,
-                   *pz = pt + (size_t)(3 * q + 2) * g.Rp;
-      ax[q] = px[lane];
-      ay[q] = py[lane];
-      az[q] = pz[lane];
-      bx[q] = px[lane + kWave];
-      by[q] = py[lane + kWave];
-      bz[q] = pz[lane + kWave];
-    }
+    for (int q = 0; q < CH; ++q)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double *pk = pt + (size_t)(3 * q + k) * g.Rp;
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) row[rr][q][k] = pk[lane + rr * kWave];
+      }
     // one running pointer walks the block's columns; `nvalid` is made opaque per chunk so that the
     // per-column strides are not hoisted out of the sample loop into spilled scalar registers
     int nvalid = ncols;
     asm volatile("" : "+s"(nvalid));
     const double *pc = pcol + ((size_t)cj * S + s0) * 3;
-    auto consume = [&](double &m0, double &m1, const ColChunk &k) {
+    auto consume = [&](int jj, const ColChunk &k) {
 #pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const double dx0 = k.minus(3 * q + 0, ax[q]), dy0 = k.minus(3 * q + 1, ay[q]), dz0 = k.minus(3 * q + 2, az[q]);
-        const double dx1 = k.minus(3 * q + 0, bx[q]), dy1 = k.minus(3 * q + 1, by[q]), dz1 = k.minus(3 * q + 2, bz[q]);
-        // the minimum by hand: behind the wait's register tie the compiler no longer knows the accumulator to
-        // be canonical and would put a v_max in front of every fmin.  Neither operand can be a signalling NaN
-        // (d2 comes out of arithmetic, m out of earlier minima), and a quiet NaN loses, as fmin's would.
-        const double d20 = __builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0));
-        const double d21 = __builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1));
-        asm("v_min_f64 %0, %1, %0" : "+v"(m0) : "v"(d20));
-        asm("v_min_f64 %0, %1, %0" : "+v"(m1) : "v"(d21));
-      }
+      for (int q = 0; q < CH; ++q)
+#pragma unroll
+        for (int rr = 0; rr < RPL; ++rr) {
+          const double dx = k.minus(3 * q + 0, row[rr][q][0]), dy = k.minus(3 * q + 1, row[rr][q][1]),
+                       dz = k.minus(3 * q + 2, row[rr][q][2]);
+          const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+          // the minimum by hand: behind the wait's register tie the compiler no longer knows the accumulator
+          // to be canonical and would put a v_max in front of every fmin.  Neither operand can be a signalling
+          // NaN (d2 comes out of arithmetic, the accumulator out of earlier minima), and a quiet NaN loses, as
+          // fmin's would.
+          asm("v_min_f64 %0, %1, %0" : "+v"(acc[rr][jj]) : "v"(d2));
+        }
     };
     // two register sets alternate: the loads of column j+1 are issued right after the wait for
-    // column j and fly during its 2 x 6 x 7 VALU operations
+    // column j and fly during its RPL x 6 x 7 VALU operations
     ColChunk ca, cb2;
     ca.fetch(pc);
 #pragma unroll
     for (int jj = 0; jj < NC; jj += 2) {
       pc += (jj + 1 < nvalid) ? stride : 0;
-      ca.wait(acc1[jj > 0 ? jj - 1 : 0]);
+      ca.wait(acc[RPL - 1][jj > 0 ? jj - 1 : 0]);
       cb2.fetch(pc);
-      consume(acc0[jj], acc1[jj], ca);
+      consume(jj, ca);
       pc += (jj + 2 < nvalid) ? stride : 0;
-      cb2.wait(acc1[jj]);
+      cb2.wait(acc[RPL - 1][jj]);
       if (jj + 2 < NC) ca.fetch(pc);
-      consume(acc0[jj + 1], acc1[jj + 1], cb2);
+      consume(jj + 1, cb2);
     }
   }
   for (int s1 = Sw; s1 < S; ++s1) {
     const double *pt = prowT + (size_t)s1 * 3 * g.Rp;
     const double *px = pt, *py = pt + g.Rp, *pz = pt + 2 * (size_t)g.Rp;
-    const double ax = px[lane], ay = py[lane], az = pz[lane];
-    const double bx = px[lane + kWave], by = py[lane + kWave], bz = pz[lane + kWave];
+    double rx[RPL], ry[RPL], rz[RPL];
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      rx[rr] = px[lane + rr * kWave];
+      ry[rr] = py[lane + rr * kWave];
+      rz[rr] = pz[lane + rr * kWave];
+    }
 #pragma unroll
     for (int jj = 0; jj < NC; ++jj) {
-      const double *pc = pcol + ((size_t)(cj + (jj < ncols ? jj : ncols - 1)) * S + s1) * 3;
-      const double cx = pc[0], cy = pc[1], cz = pc[2];
-      const double dx0 = cx - ax, dy0 = cy - ay, dz0 = cz - az, dx1 = cx - bx, dy1 = cy - by, dz1 = cz - bz;
-      acc0[jj] = __builtin_fmin(__builtin_fma(dz0, dz0, __builtin_fma(dy0, dy0, dx0 * dx0)), acc0[jj]);
-      acc1[jj] = __builtin_fmin(__builtin_fma(dz1, dz1, __builtin_fma(dy1, dy1, dx1 * dx1)), acc1[jj]);
+      const double *pcs = pcol + ((size_t)(cj + (jj < ncols ? jj : ncols - 1)) * S + s1) * 3;
+      const double cx = pcs[0], cy = pcs[1], cz = pcs[2];
+#pragma unroll
+      for (int rr = 0; rr < RPL; ++rr) {
+        const double dx = cx - rx[rr], dy = cy - ry[rr], dz = cz - rz[rr];
+        acc[rr][jj] = __builtin_fmin(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), acc[rr][jj]);
+      }
     }
   }
   // row side: columns ascend, so the lowest index wins a tie
 #pragma unroll
   for (int jj = 0; jj < NC; ++jj) {
     const int j = cj + jj;
-    acc0[jj] = (j == grow0 || jj >= ncols) ? INFINITY : acc0[jj];
-    acc1[jj] = (j == grow1 || jj >= ncols) ? INFINITY : acc1[jj];
-    if (acc0[jj] < best0) {
-      best0 = acc0[jj];
-      bestj0 = j;
-    }
-    if (acc1[jj] < best1) {
-      best1 = acc1[jj];
-      bestj1 = j;
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) {
+      acc[rr][jj] = (j == rs.grow[rr] || jj >= ncols) ? INFINITY : acc[rr][jj];
+      if (acc[rr][jj] < rs.best[rr]) {
+        rs.best[rr] = acc[rr][jj];
+        rs.bestj[rr] = j;
+      }
     }
   }
   if (two_sided) {
-    // column side: min over the 128 rows of every column of the block, with the lowest row.  Each lane
-    // first folds its own two rows (the lower row wins a tie); the 64 candidates of a column go through the
-    // LDS image [column][lane]; lane = 8 * part + column then scans an eighth of its column and the parts
-    // are folded with three exchanges.  Rows past the batch end replay row R-1 and must not win.
+    // column side: min over the kRowBlock rows of every column of the block, with the lowest row.  Each
+    // lane first folds its own rows (the lower row wins a tie); the 64 candidates of a column go through the
+    // LDS image [column][lane]; lane = kColBlock * part + column then scans its part of the column and the
+    // parts are folded with cross-lane exchanges.  Rows past the batch end replay row R-1 and must not win.
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const double v0 = live0 ? acc0[c] : INFINITY, v1 = live1 ? acc1[c] : INFINITY;
-      const bool second = v1 < v0;
-      sFold[c * kWave + lane] = second ? v1 : v0;
-      sFoldI[c * kWave + lane] = second ? lane + kWave : lane;
+      double v = rs.live[0] ? acc[0][c] : INFINITY;
+      int vi = lane;
+#pragma unroll
+      for (int rr = 1; rr < RPL; ++rr) {
+        const double o = rs.live[rr] ? acc[rr][c] : INFINITY;
+        if (o < v) {
+          v = o;
+          vi = lane + rr * kWave;
+        }
+      }
+      sFold[c * kWave + lane] = v;
+      sFoldI[c * kWave + lane] = vi;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    const int c = lane & (kColBlock - 1), part = lane >> 3;
+    constexpr int PER = kColBlock;                 // candidates a lane scans: 64 lanes / (64 / kColBlock) parts
+    const int c = lane & (kColBlock - 1), part = lane / kColBlock;
     double cm = INFINITY;
     int ci = 0;
     if (c < NC) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const double v = sFold[c * kWave + part * 8 + k];
-        const int vi = sFoldI[c * kWave + part * 8 + k];
+      for (int k = 0; k < PER; ++k) {
+        const double v = sFold[c * kWave + part * PER + k];
+        const int vi = sFoldI[c * kWave + part * PER + k];
         if (v < cm || (v == cm && vi < ci)) {
           cm = v;
           ci = vi;
@@ -722,7 +742,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       }
     }
 #pragma unroll
-    for (int mask = 8; mask <= 32; mask <<= 1) {
+    for (int mask = kColBlock; mask <= 32; mask <<= 1) {
       const double other = shfl_xor_f64(cm, mask);
       const int oi = __shfl_xor(ci, mask);
       const bool take = (other < cm) | ((other == cm) & (oi < ci));
@@ -786,13 +806,16 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
     // unit -> column: the columns left of the own range, then from the row block's own first column on
     const int diag0 = g.os + I * kRowBlock;                               // only meaningful with g.sym
     const int skip = g.sym ? I * kRowBlock : 0;                           // own-range columns not met
-    const int r0raw = I * kRowBlock + lane, r1raw = r0raw + kWave;
-    const bool live0 = r0raw < g.R, live1 = r1raw < g.R;
-    const int r0 = live0 ? r0raw : g.R - 1, r1 = live1 ? r1raw : g.R - 1;
-    const int grow0 = g.ro + r0, grow1 = g.ro + r1;
+    RowSet rs;
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerLane; ++rr) {
+      const int raw = I * kRowBlock + rr * kWave + lane;
+      rs.live[rr] = raw < g.R;
+      rs.grow[rr] = g.ro + (rs.live[rr] ? raw : g.R - 1);
+      rs.best[rr] = INFINITY;
+      rs.bestj[rr] = -1;
+    }
     const double *prowT = prow_t + (size_t)I * kRowBlock;
-    double best0 = INFINITY, best1 = INFINITY;
-    int bestj0 = -1, bestj1 = -1;
     for (int ux = ua; ux < ue;) {
       // a block: up to CB consecutive columns that do not straddle a boundary of the line
       const int cj = (g.sym && ux >= g.os) ? ux + skip : ux;
@@ -808,20 +831,19 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
       }
       const int ncols = lim < CB ? lim : CB;
       ux += ncols;
-      if (ncols <= 4)
-        collide_block<4>(g, prowT, pcol, cj, ncols, two_sided, live0, live1, grow0, grow1, I, lane, sFold, sFoldI,
-                         best0, bestj0, best1, bestj1, cpart_d2, cpart_i);
+      if (ncols <= kColBlock / 2)
+        collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else
-        collide_block<8>(g, prowT, pcol, cj, ncols, two_sided, live0, live1, grow0, grow1, I, lane, sFold, sFoldI,
-                         best0, bestj0, best1, bestj1, cpart_d2, cpart_i);
+        collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
     const size_t id = (size_t)w + I;
-    part_d2[id * kRowBlock + lane] = best0;
-    part_j[id * kRowBlock + lane] = (best0 == INFINITY) ? -1 : bestj0;
-    part_d2[id * kRowBlock + kWave + lane] = best1;
-    part_j[id * kRowBlock + kWave + lane] = (best1 == INFINITY) ? -1 : bestj1;
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerLane; ++rr) {
+      part_d2[id * kRowBlock + rr * kWave + lane] = rs.best[rr];
+      part_j[id * kRowBlock + rr * kWave + lane] = (rs.best[rr] == INFINITY) ? -1 : rs.bestj[rr];
+    }
   }
 }
 
