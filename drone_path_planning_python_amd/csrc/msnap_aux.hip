@@ -1002,12 +1002,14 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // the row-side partial buffer holds one 128-row entry per (wave, row block) pair: bound it
   while (((g.total + upw - 1) / upw + g.n_rb) * kRowBlock * 12 > ((long long)512 << 20)) upw *= 2;
   g.upw = (int)upw;
-  // The last part of the line goes out in half-size shares: when the queue runs dry the SIMDs finish
-  // within half a share of each other.  Only worth it while a SIMD sees few shares (at 4096 drones: 8).
+  // A launch that does not even fill the wave slots once (4 per SIMD: <= 2730 drones on one GPU) sends the
+  // last quarter of the line out in half-size shares, so that the SIMDs finish within half a share of each
+  // other (2048 x 91: 90-95 -> 81-89 us).  With more shares than slots the dispatcher evens things out by
+  // itself and the 4-column blocks only cost (3072: 144 -> 136 us, 4096: 230-250 -> 222-229, 6144: 477-505 -> 448).
   g.upw_tail = (int)upw;
   g.split = (g.total + upw - 1) / upw * upw;
   const long long shares = (g.total + upw - 1) / upw;
-  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares < (long long)ctx->n_cu * 4 * 24) {
+  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= (long long)ctx->n_cu * 4 * 4) {
     g.upw_tail = kColBlock / 2;
     g.split = shares * 3 / 4 * upw;
   }

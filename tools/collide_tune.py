@@ -28,7 +28,7 @@ def main():
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ref = None
     for variant in (0,):
-        for wpc in (64, 0, 64, 0):
+        for wpc in [int(x) for x in os.environ.get("WPC", "64,0,64,0").split(",")]:
             ctx.set_option("collide_waves_per_cu", wpc)
             for _ in range(25):
                 ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
