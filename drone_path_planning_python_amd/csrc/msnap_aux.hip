@@ -831,7 +831,9 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
       }
       const int ncols = lim < CB ? lim : CB;
       ux += ncols;
-      if (ncols <= kColBlock / 2)
+      if (ncols <= 2)
+        collide_block<2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
+      else if (ncols <= kColBlock / 2)
         collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else
         collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
@@ -1009,9 +1011,15 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.upw_tail = (int)upw;
   g.split = (g.total + upw - 1) / upw * upw;
   const long long shares = (g.total + upw - 1) / upw;
-  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= (long long)ctx->n_cu * 4 * 4) {
+  const long long slots = (long long)ctx->n_cu * 4 * 4;
+  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= slots) {
     g.upw_tail = kColBlock / 2;
     g.split = shares * 3 / 4 * upw;
+  } else if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares % slots != 0 && shares % slots <= slots / 4) {
+    // a few shares more than whole rounds of the slots (4096 drones: 8448 on 4096): left whole they would run
+    // as a last round of their own; as 2-column shares they are one short round spread over all SIMDs
+    g.upw_tail = 2;
+    g.split = (shares - shares % slots) * upw;
   }
   waves = g.split / upw + (g.total - g.split + g.upw_tail - 1) / g.upw_tail;
   if (upw > 0x3fffffff || waves > 0x7fffffff) return MSNAP_EINVAL;
