@@ -491,9 +491,10 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // implementation exists.
 //
 // Arithmetic.  One lane per TWO row drones (row blocks of 128: rows lane and lane + 64); the column
-// drone is wave-uniform, its samples arrive through scalar loads and are SGPR operands of the 9
-// operations per pair and sample (3 differences, 3 products, 2 sums -- no FMA: bit-exact with the
-// NumPy oracle, which decides ties between equidistant formation neighbours -- and the minimum).
+// drone is wave-uniform, its samples arrive through scalar loads and are SGPR operands of the 7
+// operations per pair and sample: 3 differences, d2 = fma(dz, dz, fma(dy, dy, dx * dx)) -- the
+// definition of include/msnap.h, restated bit for bit by both oracles, which is what decides ties
+// between equidistant formation neighbours -- and the minimum.
 // The running minima of a block of 8 columns stay in registers over all samples.  A scalar load has
 // only an all-or-nothing wait, so a wave has ONE column fetch (6 samples, 2 x 42 operations) in
 // flight while it computes the previous one; the other waves of the SIMD (4 fit) cover the rest of
