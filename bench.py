@@ -61,6 +61,8 @@ VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
 PAIR_OPS = 7                   # vector instructions per pair and sample: 3 differences, 1 product, 2 FMAs, 1 minimum
 PAIR_FLOPS = 9                 # the same as floating-point operations (an FMA counts two)
+PAIR_MIX_ATTAINABLE = 0.897    # the 7-instruction mix alone, 4 waves per SIMD: 4.46 nominal cycles per wave-instruction
+                               # (tools/micro/f64_rate_micro.hip: the SIMDs run at ~2.15 GHz under sustained fp64 load)
 
 
 def algorithmic_bytes(n_drones: int, n_seg: int, order: int) -> int:
@@ -488,11 +490,13 @@ def run_formation_config(cfg, env, reps, warm):
                          "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "tflops": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
+                         "frac_of_attainable": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS / PAIR_MIX_ATTAINABLE,
                          "note": "frac counts each unordered pair once (N(N-1)/2 x S x 7 vector instructions: 3 "
                                  "differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md 8d) against "
                                  "the fp64 issue peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); tflops counts the same "
                                  "work as 9 flops per pair-sample (peak 78.6 with nothing but FMAs), "
-                                 "per GPU; frac_executed counts the pair-samples the kernel evaluates"},
+                                 "per GPU; frac_executed counts the pair-samples the kernel evaluates; frac_of_attainable divides "
+                                 "frac by what the bare instruction mix reaches (0.897: tools/micro/f64_rate_micro.hip)"},
         },
     }
     if world > 1:
