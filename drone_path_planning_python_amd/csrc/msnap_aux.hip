@@ -1016,9 +1016,11 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= slots) {
     g.upw_tail = kColBlock / 2;
     g.split = shares * 3 / 4 * upw;
-  } else if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares % slots != 0 && shares % slots <= slots / 4) {
+  } else if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares % slots != 0 && shares % slots <= slots / 8) {
     // a few shares more than whole rounds of the slots (4096 drones: 8448 on 4096): left whole they would run
     // as a last round of their own; as 2-column shares they are one short round spread over all SIMDs
+    // (4096 x 91: 217 -> 207 us; with 704 of 4800 shares beyond the round at 3072 drones the 2-column blocks
+    // cost more than they even out: 136 -> 153 us, hence the limit of an eighth of the slots)
     g.upw_tail = 2;
     g.split = (shares - shares % slots) * upw;
   }
