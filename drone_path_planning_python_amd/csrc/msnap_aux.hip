@@ -527,6 +527,7 @@ struct CollideGeom {
   int upw;                  // (row block, column) units per share
   int upw_tail;             // units per share behind `split` (smaller shares even out the end of the launch)
   long long split;          // first unit of the tail shares (a multiple of upw)
+  int sparts;               // sample parts: a share of the line is taken by `sparts` waves, each a range of chunks
   long long total;          // units of the launch
 };
 
@@ -602,7 +603,7 @@ struct RowSet {
 template <int NC>
 __device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ prowT,
                                               const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
-                                              RowSet &rs, int I, int lane, double *sFold, int *sFoldI,
+                                              RowSet &rs, int I, int h, int lane, double *sFold, int *sFoldI,
                                               double *__restrict__ cpart_d2, int32_t *__restrict__ cpart_i) {
 #pragma clang fp contract(off)
   constexpr int CH = kSampleChunk, RPL = kRowsPerLane;
@@ -618,7 +619,10 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
   // a sample twice), so that every chunk takes the wide scalar loads.
   const int rem = S % CH;
   const int Sw = (rem == 1 || rem == 2) ? S - rem : S;
-  for (int sc = 0; sc < Sw; sc += CH) {
+  // sample part h of g.sparts takes its range of whole chunks (the last part also the plain remainder)
+  const int nch = (Sw + CH - 1) / CH;
+  const int sc_begin = (int)((long long)nch * h / g.sparts) * CH, sc_end = (int)((long long)nch * (h + 1) / g.sparts) * CH;
+  for (int sc = sc_begin; sc < sc_end; sc += CH) {
     const int s0 = (Sw - sc < CH) ? Sw - CH : sc;
     double row[RPL][CH][3];
     // the rows come from the transposed image [sample][xyz][row]: the 64 lanes of a load read 512
@@ -670,7 +674,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       consume(jj + 1, cb2);
     }
   }
-  for (int s1 = Sw; s1 < S; ++s1) {
+  for (int s1 = (h == g.sparts - 1) ? Sw : S; s1 < S; ++s1) {
     const double *pt = prowT + (size_t)s1 * 3 * g.Rp;
     const double *px = pt, *py = pt + g.Rp, *pz = pt + 2 * (size_t)g.Rp;
     double rx[RPL], ry[RPL], rz[RPL];
@@ -751,7 +755,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       ci = take ? oi : ci;
     }
     if (part == 0 && c < ncols) {
-      const size_t slot = (size_t)I * g.R + (size_t)(cj + c - g.os);
+      const size_t slot = ((size_t)I * g.sparts + h) * g.R + (size_t)(cj + c - g.os);
       cpart_d2[slot] = cm;
       cpart_i[slot] = (cm == INFINITY) ? -1 : g.ro + I * kRowBlock + ci;
     }
@@ -792,7 +796,7 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
-  const int w = blockIdx.x;
+  const int w = blockIdx.x / g.sparts, h = blockIdx.x - w * g.sparts;
   long long u = collide_share_begin(g, w);
   const long long u_end = collide_share_begin(g, (long long)w + 1);
   if (u >= u_end) return;
@@ -833,15 +837,15 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
       const int ncols = lim < CB ? lim : CB;
       ux += ncols;
       if (ncols <= 2)
-        collide_block<2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else if (ncols <= kColBlock / 2)
-        collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else
-        collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
-    const size_t id = (size_t)w + I;
+    const size_t id = ((size_t)w + I) * g.sparts + h;
 #pragma unroll
     for (int rr = 0; rr < kRowsPerLane; ++rr) {
       part_d2[id * kRowBlock + rr * kWave + lane] = rs.best[rr];
@@ -928,10 +932,10 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
     // row side: the shares that met this drone's row block
     const int I = r / kRowBlock;
     const long long wf = collide_share_of(g, collide_ustart(g, I)), wl = collide_share_of(g, collide_ustart(g, I + 1) - 1);
-    const size_t first = ((size_t)wf + I) * kRowBlock + (r - I * kRowBlock);
-    sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1));
-    // column side: the row blocks before this drone's own
-    if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I);
+    const size_t first = ((size_t)wf + I) * g.sparts * kRowBlock + (r - I * kRowBlock);
+    sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1) * g.sparts);
+    // column side: the row blocks before this drone's own (each left `sparts` entries per column)
+    if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * g.sparts);
   }
   sD[q][lr] = best;
   sJ[q][lr] = bj;
@@ -963,6 +967,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.S = n_samples;
   g.n_rb = (n_rows + kRowBlock - 1) / kRowBlock;
   g.Rp = g.n_rb * kRowBlock;
+  g.sparts = 1;
   if (n_cols == 0) {
     // nobody to collide with: the merge of nothing writes inf / -1 / 0
     g.os = g.oe = 0;
@@ -997,6 +1002,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // per-block prologue and fold than they gain (4096 x 91: 288 -> 340 us); a share that ends inside a
   // block pays for the whole block.  "collide_waves_per_cu" (tuning tools) asks for fewer, longer shares.
   long long upw = kColBlock;
+  const long long slots = (long long)ctx->n_cu * 4 * 4;      // resident waves: 4 per SIMD
   if (ctx->collide_waves_per_cu > 0) {
     upw = g.total / ((long long)ctx->n_cu * ctx->collide_waves_per_cu) / kColBlock * kColBlock;
     if (upw < kColBlock) upw = kColBlock;
@@ -1007,13 +1013,13 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.upw = (int)upw;
   // A launch that does not even fill the wave slots once (4 per SIMD: <= 2730 drones on one GPU) sends the
   // last quarter of the line out in half-size shares, so that the SIMDs finish within half a share of each
-  // other (2048 x 91: 90-95 -> 81-89 us).  With more shares than slots the dispatcher evens things out by
+  // other (2048 x 91: 90-95 -> 81-89 us; a shard's rows against all columns -- equal one-sided blocks -- lose by
+  // it: 1024 of 4096 rows 109-117 -> 120-133 us, so whole swarms only).  With more shares than slots the dispatcher evens things out by
   // itself and the 4-column blocks only cost (3072: 144 -> 136 us, 4096: 230-250 -> 222-229, 6144: 477-505 -> 448).
   g.upw_tail = (int)upw;
   g.split = (g.total + upw - 1) / upw * upw;
   const long long shares = (g.total + upw - 1) / upw;
-  const long long slots = (long long)ctx->n_cu * 4 * 4;
-  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= slots) {
+  if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares <= slots && n_rows == n_cols) {
     g.upw_tail = kColBlock / 2;
     g.split = shares * 3 / 4 * upw;
   } else if (upw == kColBlock && ctx->collide_waves_per_cu == 0 && shares % slots != 0 && shares % slots <= slots / 8) {
@@ -1025,9 +1031,17 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.split = (shares - shares % slots) * upw;
   }
   waves = g.split / upw + (g.total - g.split + g.upw_tail - 1) / g.upw_tail;
-  if (upw > 0x3fffffff || waves > 0x7fffffff) return MSNAP_EINVAL;
-  const size_t part_entries = ((size_t)waves + g.n_rb) * kRowBlock;
-  const size_t centries = g.sym ? cpart_entries : 0;
+  // A small launch (a small swarm, or one of many shards) is as long as ONE share takes -- 16 sample chunks x 8
+  // columns are one dependent chain of scalar fetches, 43 us at 512 drones whatever the arithmetic.  While the
+  // shares do not fill a quarter of the wave slots (half-full launches lose: 512 of 4096 rows 71 -> 84 us), each
+  // is taken by 2, 4 or 8 waves with a range of the sample chunks each (narrower column blocks instead would repeat the row loads per block: 1024 drones 46 -> 59 us).
+  if (ctx->collide_waves_per_cu == 0) {
+    const int nch = (n_samples + kSampleChunk - 1) / kSampleChunk;
+    while (g.sparts < 8 && waves * g.sparts < slots / 4 && nch / (g.sparts * 2) >= 2) g.sparts *= 2;
+  }
+  if (upw > 0x3fffffff || waves * g.sparts > 0x7fffffff) return MSNAP_EINVAL;
+  const size_t part_entries = ((size_t)waves + g.n_rb) * g.sparts * kRowBlock;
+  const size_t centries = g.sym ? cpart_entries * g.sparts : 0;
   const int E = n_samples * 3;
   const size_t t_entries = (size_t)g.Rp * E;
   int rc = ensure(ctx, ctx->stage[7],
@@ -1041,7 +1055,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
                      n_rows, g.Rp, E, rows_t);
   MSNAP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)waves), dim3(kWave), 0, ctx->stream,
+  hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
                      (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,

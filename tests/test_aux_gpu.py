@@ -126,12 +126,14 @@ def test_formation_collide_against_oracle(ctx7):
                                       (333, 23, 0, 64), (333, 23, 269, 64), (500, 4, 130, 370), (97, 3, 0, 97),
                                       (1000, 13, 0, 1000), (1000, 13, 640, 200), (129, 40, 0, 129),
                                       (128, 7, 0, 128), (257, 12, 0, 257), (260, 6, 128, 130), (135, 19, 3, 129),
-                                      (200, 8, 0, 200), (140, 14, 5, 130), (150, 20, 0, 150)])
+                                      (200, 8, 0, 200), (140, 14, 5, 130), (150, 20, 0, 150),
+                                      (100, 91, 0, 100), (300, 96, 37, 200), (260, 49, 0, 260)])
 def test_formation_collide_tiles(ctx7, n, s, ro, r):
     """The span kernel: pairs inside the rows' own column range are evaluated once and credited to
     both drones (column-side minima through the per-wave LDS fold), everything else one-sidedly.
     Row counts around the 128-row (two rows per lane) / 8-column block edges, shards at unaligned
-    offsets, sample counts around the 6-sample chunk, with exact ties between equidistant neighbours
+    offsets, sample counts around the 6-sample chunk, paths long enough for a small launch to split its
+    shares over 2 - 8 sample parts, with exact ties between equidistant neighbours
     (lattice positions): distances, partners (lowest index wins) and hits must equal the oracle's bit
     for bit."""
     rng = np.random.default_rng(1000 * n + s)

@@ -18,12 +18,15 @@ VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     S = int(sys.argv[2]) if len(sys.argv) > 2 else 91
+    R = int(sys.argv[3]) if len(sys.argv) > 3 else N          # rows of a shard (default: all)
+    RO = int(sys.argv[4]) if len(sys.argv) > 4 else 0         # its first global row
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(5)
     pos = torch.from_numpy(rng.uniform(-50, 50, size=(N, S, 3))).to(dev)
-    md = torch.empty((N,), dtype=torch.float64, device=dev)
-    partner = torch.empty((N,), dtype=torch.int32, device=dev)
-    hit = torch.empty((N,), dtype=torch.int32, device=dev)
+    md = torch.empty((R,), dtype=torch.float64, device=dev)
+    partner = torch.empty((R,), dtype=torch.int32, device=dev)
+    hit = torch.empty((R,), dtype=torch.int32, device=dev)
+    rows = pos[RO:RO + R].contiguous()
     ctx = Context(0, 7, 16)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ref = None
@@ -31,13 +34,13 @@ def main():
         for wpc in [int(x) for x in os.environ.get("WPC", "64,0,64,0").split(",")]:
             ctx.set_option("collide_waves_per_cu", wpc)
             for _ in range(25):
-                ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
+                ctx.formation_collide_device(R, RO, N, S, rows, pos, 0.15, md, partner, hit)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 20
             e0.record()
             for _ in range(reps):
-                ctx.formation_collide_device(N, 0, N, S, pos, pos, 0.15, md, partner, hit)
+                ctx.formation_collide_device(R, RO, N, S, rows, pos, 0.15, md, partner, hit)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / reps * 1e3
@@ -45,8 +48,9 @@ def main():
             if ref is None:
                 ref = out
             same = np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
-            alg = N * (N - 1) / 2 * S * 7        # 3 differences, 1 product, 2 FMAs, 1 minimum
-            print(json.dumps({"N": N, "S": S, "waves_per_cu": wpc, "us": round(us, 1),
+            # a shard evaluates its rows against the other columns, its own block once per pair
+            alg = (R * (N - R) + R * (R - 1) / 2) * S * 7      # 3 differences, 1 product, 2 FMAs, 1 minimum
+            print(json.dumps({"N": N, "S": S, "rows": R, "waves_per_cu": wpc, "us": round(us, 1),
                               "frac_of_f64_issue_peak_on_unordered_pairs": round(alg / (us * 1e-6) / VALU_F64_OPS, 3),
                               "same_result": bool(same)}), flush=True)
     ctx.close()
