@@ -1035,7 +1035,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // columns are one dependent chain of scalar fetches, 43 us at 512 drones whatever the arithmetic.  While the
   // shares do not fill a quarter of the wave slots (half-full launches lose: 512 of 4096 rows 71 -> 84 us), each
   // is taken by 2, 4 or 8 waves with a range of the sample chunks each (narrower column blocks instead would repeat the row loads per block: 1024 drones 46 -> 59 us).
-  if (ctx->collide_waves_per_cu == 0) {
+  if (ctx->collide_sample_parts > 0) {
+    g.sparts = ctx->collide_sample_parts < 8 ? ctx->collide_sample_parts : 8;
+  } else if (ctx->collide_waves_per_cu == 0) {
     const int nch = (n_samples + kSampleChunk - 1) / kSampleChunk;
     while (g.sparts < 8 && waves * g.sparts < slots / 4 && nch / (g.sparts * 2) >= 2) g.sparts *= 2;
   }

@@ -78,6 +78,7 @@ struct msnap_ctx {
   int gemm_grid_waves = 0;      // "gemm_grid_waves": cap on the shared-grid GEMM's persistent grid (0: default)
   void *mesh_tests = nullptr;   // "mesh_count_tests": device counter of the point-triangle tests evaluated (not culled)
   int collide_waves_per_cu = 0; // "collide_waves_per_cu": shares per CU of the pairwise pass (0: one column block per share)
+  int collide_sample_parts = 0; // "collide_sample_parts": waves per share of the pairwise pass (0: chosen per launch)
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
   char hip_err[256] = {0};
 };

@@ -85,6 +85,8 @@ int msnap_host_free(void *ptr);
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
  *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 8-column x 128-row block per share)
+ *   "collide_sample_parts" waves per share of the pairwise pass, each a range of the sample chunks
+ *                          (0 = chosen per launch: more than one only when the launch is small)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
