@@ -149,6 +149,27 @@ def test_formation_collide_tiles(ctx7, n, s, ro, r):
     np.testing.assert_array_equal(hit, rhit[ro:ro + r])
 
 
+@pytest.mark.parametrize("parts", [2, 4, 8])
+def test_formation_collide_sample_parts(ctx7, parts):
+    """Every share taken by several waves with a range of the sample chunks each (what a small launch
+    does by itself), forced on a swarm big enough to have two-sided blocks and several row blocks:
+    row-side and column-side partial minima of the parts must merge to the oracle's answer."""
+    rng = np.random.default_rng(900 + parts)
+    pos = rng.uniform(-3.0, 3.0, size=(700, 55, 3))
+    pos[:200] = np.round(pos[:200] * 2.0) / 2.0
+    ref = O.formation_collide(pos, 0.3)
+    ctx7.set_option("collide_sample_parts", parts)
+    try:
+        got = ctx7.formation_collide(pos, pos, 0.3)
+        shard = ctx7.formation_collide(pos[300:650], pos, 0.3, row_offset=300)
+    finally:
+        ctx7.set_option("collide_sample_parts", 0)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(shard, ref):
+        np.testing.assert_array_equal(a, b[300:650])
+
+
 def test_formation_collide_rows_not_among_columns(ctx7):
     """rows beyond the columns (row_offset + n_rows > n_cols): one-sided everywhere, no self to exclude."""
     rng = np.random.default_rng(77)
