@@ -73,6 +73,19 @@ class DeviceCompute:
             self.ctx.solve_batch_device(n, M, wp, t, t.dim() == 1, coef, dur, status)
         return coef, dur, status
 
+    def solve_grid(self, wp):
+        """The same solve on the shared time grid the context was prepared for (`Context.prepare_grid`): one
+        fp64 MFMA GEMM against the grid's operator instead of the per-drone recurrence."""
+        torch = self.torch
+        n, m, _ = wp.shape
+        M = m - 1
+        coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
+        dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
+        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if n:
+            self.ctx.solve_grid_device(n, wp, coef, dur, status)
+        return coef, dur, status
+
     def sample(self, coef, dur, dt, n_samples):
         torch = self.torch
         n, M = dur.shape
