@@ -170,6 +170,28 @@ def test_formation_collide_sample_parts(ctx7, parts):
         np.testing.assert_array_equal(a, b[300:650])
 
 
+def test_formation_collide_seeded_shapes(ctx7):
+    """Thirty seeded shapes (swarm size, sample count, shard position and length drawn at random; a lattice
+    part for exact ties) against the C oracle, bit for bit: the shape-dependent paths of the launch -- block
+    instances of 2 / 4 / 8 columns, plain remainder samples or an overlapped last chunk, sample parts of
+    small launches, shards that start and end inside row blocks -- in combinations nobody listed by hand."""
+    import c_oracle
+    rng = np.random.default_rng(20260104)
+    for _ in range(30):
+        n = int(rng.integers(2, 900))
+        s = int(rng.integers(1, 70))
+        pos = rng.uniform(-4.0, 4.0, size=(n, s, 3))
+        k = n // 4
+        pos[:k] = np.round(pos[:k] * 2.0) / 2.0
+        ref = c_oracle.formation_collide(pos, 0.25)
+        ro = int(rng.integers(0, n))
+        r = int(rng.integers(1, n - ro + 1))
+        for lo, cnt in ((0, n), (ro, r)):
+            got = ctx7.formation_collide(pos[lo:lo + cnt], pos, 0.25, row_offset=lo)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b[lo:lo + cnt], err_msg=f"n={n} s={s} rows=[{lo},{lo + cnt})")
+
+
 def test_formation_collide_rows_not_among_columns(ctx7):
     """rows beyond the columns (row_offset + n_rows > n_cols): one-sided everywhere, no self to exclude."""
     rng = np.random.default_rng(77)
