@@ -954,6 +954,577 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 }
 
 // ------------------------------------------------------------------------------------
+// order-9 throughput variant for n_seg <= MAXM: the matrix part of the recurrence split by
+// COLUMN over the 4 axis lanes of a drone (order 9: NU = 4 unknown derivatives per knot = 4
+// lanes).  Lane a solves column a of G_i = S_i^-1 O_i and forms column a of the Schur term
+// O_i^T G_i (plus its own axis' z_i and O_i^T z_i) instead of all four lanes carrying all 16
+// entries; the symmetric Schur block of the next knot is gathered with quad-broadcast DPP moves.
+// What a lane keeps of the previous segment is its 7 powers of 1/T (the end-side block
+// E = HEE * powers is folded into the FMAs that build S) and the 4 end-side right-hand terms.
+// All inputs of the tile go to registers at the tile top (the 10 reciprocals run side by side,
+// off the recurrence), so the input stage is dead before the first G column is stashed and the
+// LDS image is  [ pad | G slots, last knot first ]  with the output transposition image on top of
+// the pad and the LAST slot, which the backward sweep has consumed before its first store:
+// 19.8 KB per wave at n_seg = 10 and <= 256 registers -> two waves per SIMD, 8 per CU
+// (solve_kernel_reg<5,10>: 307 registers, 23.4 KB, one wave per SIMD).
+// ------------------------------------------------------------------------------------
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {   // lane SRC of the quad to all four
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, SRC * 0x55, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, SRC * 0x55, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int kQuadSlotWords = 16 * 16;                                  // one knot's G: 16 entries x 16 drones
+constexpr int kQuadTrWords = 5 * kTrPitch * 2;                           // output transposition image (NC/2 = 5 rows)
+constexpr int kQuadPadWords = kQuadTrWords - kQuadSlotWords;
+inline size_t quad9_lds_bytes(int n_seg) {
+  const size_t in_words = solve_input_words(n_seg);
+  const size_t g_words = (size_t)kQuadPadWords + (size_t)(n_seg > 2 ? n_seg - 2 : 0) * kQuadSlotWords;
+  const size_t tr_words = kQuadTrWords;
+  size_t w = in_words > g_words ? in_words : g_words;
+  if (tr_words > w) w = tr_words;
+  return w * sizeof(double);
+}
+
+template <int MAXM>
+__global__ void __launch_bounds__(kWave, 2)
+solve_kernel_quad9(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+                   int N, int M, double *__restrict__ coef, double *__restrict__ dur,
+                   int32_t *__restrict__ status, int ntiles) {
+  constexpr int K = 5;
+  using SW = Sweep<K>;
+  using C = HermiteConsts<K>;
+  constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
+  static_assert(NU == kAxes, "one column of the knot blocks per axis lane");
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int lane0 = threadIdx.x;
+  const int wpitch = (M + 1) * 4;
+  const int tpitch = M + 1;
+  double *sWraw = lds;
+  double *sTraw = sWraw + 16 * wpitch;
+  double2 *sTr = reinterpret_cast<double2 *>(lds);
+  // G of knot i (1 <= i <= M-2) lives in slot i-1; slot M-3 (the last one written, the first one read
+  // back) sits right behind the pad, slot 0 at the far end
+  double *sGlast = lds + kQuadPadWords;
+  auto slot = [&](int s) { return sGlast + (M - 3 - s) * kQuadSlotWords; };
+
+  auto tile_valid = [&](int tl) {
+    const int left = N - tl * kDronesPerWave;
+    return left < kDronesPerWave ? left : kDronesPerWave;
+  };
+  StageRegsAsm<MAXM> pre;
+  if ((int)blockIdx.x < ntiles)
+    stage_load_asm(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane0, pre);
+  wait_vmcnt<0>();
+  constexpr int kStoresPerSeg = NC / 2;   // see solve_kernel_reg: the same cross-tile prefetch and exact wait
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Everything derived from the lane index is rebuilt per tile from an opaque copy: left to the
+    // compiler, two dozen loop-invariant addresses are hoisted out of the tile loop and live -- spilled --
+    // across the whole tile, which costs more than recomputing them once per ~5 000 instructions.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int dl = lane >> 2;
+    const int a = lane & 3;
+    // this lane's column of the coupling block: O_i[n][a] = HSE[n+1][a+1] x^(7-n-a)
+    double ca[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n)
+      ca[n] = a == 0 ? C::HSE[n + 1][1] : a == 1 ? C::HSE[n + 1][2] : a == 2 ? C::HSE[n + 1][3] : C::HSE[n + 1][4];
+    const int d_raw = tile * kDronesPerWave + dl;
+    const bool live = d_raw < N;
+    const int d = live ? d_raw : N - 1;
+    const int nvalid = tile_valid(tile);
+    const int next = tile + gridDim.x;
+
+    asm volatile("s_setprio 0" ::: "memory");   // tile-top marker for tools/check_prefetch_isa.py
+    wave_lds_fence();
+    stage_wait_asm<MAXM, 2 * kStoresPerSeg>(pre);
+    stage_store_asm(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
+    wave_lds_fence();
+    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
+    const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
+    const double *lw = sWraw + dloc * wpitch + a;
+    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
+
+    // ---- the whole path into registers: waypoints, 1/T (indices past the path end replay its last
+    // entry: T = 0 there, never used) ----
+    double wreg[MAXM + 1], xreg[MAXM], zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
+    const double t0 = lt[0];
+    bool nonfinite = !finite64(t0);
+    bool badtime = t0 < 0.0;
+    {
+      double treg[MAXM + 1];
+      treg[0] = t0;
+#pragma unroll
+      for (int i = 0; i <= MAXM; ++i) {
+        const int j = i <= M ? i : M;
+        wreg[i] = lw[j * 4];
+        if (i >= 1) treg[i] = lt[j];
+      }
+#pragma unroll
+      for (int i = 0; i <= MAXM; ++i) nonfinite |= !finite64(wreg[i]) | !finite64(treg[i]);
+#pragma unroll
+      for (int i = 0; i < MAXM; ++i) {
+        double T = treg[i + 1] - treg[i];
+        badtime |= (i < M) & !(T > 0.0);
+        if (i == 0) {
+          T -= t0;   // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
+          badtime |= !(T > 0.0);
+        }
+        xreg[i] = rcp64(T);
+      }
+    }
+    wave_lds_fence();   // the input stage is dead from here on: the G slots alias it
+
+    // ---- forward sweep ----
+    double xpp[PM], re[NU], OtG[NS], Otz[NU];   // xpp[p-1] = (1/T_{i-1})^p
+    {
+      double xp[PM + 1];
+      SW::powers(xreg[0], xp);
+      const double dw0 = wreg[1] - wreg[0];
+#pragma unroll
+      for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
+#pragma unroll
+      for (int n = 1; n <= NU; ++n) re[n - 1] = C::HEE[n][0] * (xp[KK - n] * dw0);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
+#pragma unroll
+      for (int r = 0; r < NU; ++r) Otz[r] = 0.0;
+    }
+    bool singular = false;
+#pragma unroll
+    for (int i = 1; i < MAXM; ++i) {
+      if (i < M) {
+        double xp[PM + 1];
+        SW::powers(xreg[i], xp);
+        const double dw = wreg[i + 1] - wreg[i];
+        double S[NS], y[NU];
+#pragma unroll
+        for (int n = 1; n <= NU; ++n) {
+#pragma unroll
+          for (int m = 1; m <= n; ++m)
+            S[sidx(n - 1, m - 1)] = __builtin_fma(
+                C::HSS[n][m], xp[KK - n - m],
+                __builtin_fma(C::HEE[n][m], xpp[KK - n - m - 1], -OtG[sidx(n - 1, m - 1)]));
+          const double tdw = xp[KK - n] * dw;
+          y[n - 1] = __builtin_fma(-C::HSE[n][0], tdw, -(re[n - 1] + Otz[n - 1]));
+          re[n - 1] = C::HEE[n][0] * tdw;
+        }
+        double dinv[NU];
+        singular |= SW::ldl_factor(S, dinv);
+
+        // own column of O_i, then the two solves of this lane: G column and z
+        const double pa = a == 0 ? xp[4] : a == 1 ? xp[3] : a == 2 ? xp[2] : xp[1];
+        double g[NU];
+#pragma unroll
+        for (int n = 0; n < NU; ++n) g[n] = ca[n] * (n == NU - 1 ? pa : pa * xp[NU - 1 - n]);
+        SW::ldl_solve(S, dinv, g);
+        SW::ldl_solve(S, dinv, y);
+        if (i < M - 1) {
+          double *gs = slot(i - 1) + a * 16 + dl;
+#pragma unroll
+          for (int r = 0; r < NU; ++r) gs[r * NU * 16] = g[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) zreg[i - 1][r] = y[r];
+
+        // Schur terms for knot i+1: column a of O^T G and O^T z,
+        //   sum_q HSE[q][n] x^(9-q-n) v[q] = x^(5-n) sum_q HSE[q][n] (x^(4-q) v[q])
+#pragma unroll
+        for (int q = 0; q < NU - 1; ++q) {
+          g[q] *= xp[NU - 1 - q];
+          y[q] *= xp[NU - 1 - q];
+        }
+        double col[NU];
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          double sg = C::HSE[1][n + 1] * g[0], sz = C::HSE[1][n + 1] * y[0];
+#pragma unroll
+          for (int q = 1; q < NU; ++q) {
+            sg = __builtin_fma(C::HSE[q + 1][n + 1], g[q], sg);
+            sz = __builtin_fma(C::HSE[q + 1][n + 1], y[q], sz);
+          }
+          col[n] = sg * xp[NU - n];
+          Otz[n] = sz * xp[NU - n];
+        }
+#pragma unroll
+        for (int n = 0; n < NU; ++n) {
+          OtG[sidx(n, 0)] = quad_bcast<0>(col[n]);
+          if (n >= 1) OtG[sidx(n, 1)] = quad_bcast<1>(col[n]);
+          if (n >= 2) OtG[sidx(n, 2)] = quad_bcast<2>(col[n]);
+          if (n >= 3) OtG[sidx(n, 3)] = quad_bcast<3>(col[n]);
+        }
+#pragma unroll
+        for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
+      }
+    }
+
+    const int st = drone_status(nonfinite, badtime, singular);
+    if (live && a == 0) status[d] = st;
+    const bool bad = st != 0;
+
+    // ---- backward sweep + recovery (as solve_kernel_reg) ----
+    double un[NU], gq[NU][NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      un[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NU; ++c) gq[r][c] = 0.0;
+    }
+#pragma unroll
+    for (int i = MAXM - 1; i >= 0; --i) {
+      if (i == (MAXM >= 2 ? 1 : 0)) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = next < ntiles ? next : ntiles - 1;
+        stage_load_asm(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
+      }
+      if (i <= 1 || i < M) {
+        double u[NU];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+          double v = (i >= 1) ? zreg[i >= 1 ? i - 1 : 0][r] : 0.0;
+          if (i >= 1) {
+#pragma unroll
+            for (int c = 0; c < NU; ++c) v = __builtin_fma(-gq[r][c], un[c], v);
+          }
+          u[r] = v;
+        }
+        if (i >= 2) {   // G of knot i-1 (slot i-2) for the next iteration
+          const double *gsl = slot(i - 2) + dl;
+#pragma unroll
+          for (int r = 0; r < NU; ++r)
+#pragma unroll
+            for (int c = 0; c < NU; ++c) gq[r][c] = gsl[(r * NU + c) * 16];
+        }
+        double c[NC];
+        recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], xreg[i], u, un, c);
+        if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+        store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
+                                    lane, c, bad);
+#pragma unroll
+        for (int r = 0; r < NU; ++r) un[r] = u[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// order-9 throughput variant, two-sided AND column-split ("twin"): lane = 8*drone + 4*side + axis,
+// 8 drones per wavefront.  The per-lane state a solve must keep between its two sweeps (z_i, the
+// waypoints, 1/T) is what pushes the one-sided order-9 kernels beyond 256 registers; with the knots
+// of a path shared between two sides every lane keeps half of it, the dependent chain is half as
+// long, and with the column split (solve_kernel_quad9 above) the G columns go to LDS as they are
+// made: <= 256 registers and 13.6 KB of LDS -> two waves per SIMD.  The merge at the meeting knot and
+// the reversed-time bookkeeping of side 1 are those of solve_kernel_twist below.  One instance per
+// even segment count (both sides own (M-2)/2 knots and M/2 segments).
+// ------------------------------------------------------------------------------------
+constexpr int kTwinDrones = 8;
+
+// 16 (drone, side) blocks of 4 lanes x 10 coefficients: through the LDS image so that every store
+// instruction writes whole 64-byte segments of the blocks' 320 bytes
+__device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__restrict__ coef, int tile, int M,
+                                                     int it, int nvalid, int lane, const double (&c)[10]) {
+  constexpr int NJ = 5;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sTr[j * kTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+#pragma unroll
+  for (int q = 0; q < NJ; ++q) {
+    const int s = q * kWave + lane;          // flat 16-byte slot of the wave's 16 blocks
+    const int blk = s / (4 * NJ);
+    const int within = s - blk * (4 * NJ);
+    const int a2 = within / NJ;
+    const int j2 = within - a2 * NJ;
+    const double2 v = sTr[j2 * kTrPitch + blk * 4 + a2];
+    const int drone = blk >> 1;
+    const int seg = (blk & 1) ? M - 1 - it : it;
+    // drones past the batch end replay the tile's last valid one (bitwise the same values): stored on top of it
+    const int dd = drone < nvalid ? drone : nvalid - 1;
+    double *dst = coef + ((size_t)(tile * kTwinDrones + dd) * M + seg) * (4 * 2 * NJ) + within * 2;
+    *reinterpret_cast<double2 *>(dst) = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+}
+
+inline size_t twin9_lds_bytes(int n_seg) {
+  const size_t h = (size_t)(n_seg - 2) / 2;
+  const size_t g_words = h * kQuadSlotWords;                  // h knots x 16 entries x 16 (drone, side) blocks
+  const size_t in_words = (size_t)kTwinDrones * (n_seg + 1) * 5;
+  const size_t body = (size_t)kQuadTrWords + g_words;
+  return (in_words > body ? in_words : body) * sizeof(double);
+}
+
+template <int M>
+__global__ void __launch_bounds__(kWave, 2)
+solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+                   int N, double *__restrict__ coef, double *__restrict__ dur,
+                   int32_t *__restrict__ status, int ntiles) {
+  constexpr int K = 5;
+  using SW = Sweep<K>;
+  using C = HermiteConsts<K>;
+  constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
+  static_assert(NU == kAxes, "one column of the knot blocks per axis lane");
+  static_assert(M >= 2 && (M % 2) == 0, "both sides own (M-2)/2 knots");
+  constexpr int H = (M - 2) / 2;              // knots per side; the meeting knot is knot H+1 of both
+  constexpr int HA = H > 0 ? H : 1;
+
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+
+  const int lane0 = threadIdx.x;
+  constexpr int wpitch = (M + 1) * 4;
+  constexpr int tpitch = M + 1;
+  // LDS: [ transposition image | G: [knot][entry][16 blocks] ]; the input stage aliases both (dead before the first use)
+  double *sWraw = lds;
+  double *sTraw = sWraw + kTwinDrones * wpitch;
+  double2 *sTr = reinterpret_cast<double2 *>(lds);
+  double *sG = lds + kQuadTrWords;
+  double dsg[NU];
+#pragma unroll
+  for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // everything derived from the lane index is rebuilt per tile from an opaque copy (see solve_kernel_quad9)
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int a = lane & 3;
+    const int side = (lane >> 2) & 1;
+    const int blk = lane >> 2;                  // (drone, side)
+    const int dl = lane >> 3;
+    double ca[NU];
+#pragma unroll
+    for (int n = 0; n < NU; ++n)
+      ca[n] = a == 0 ? C::HSE[n + 1][1] : a == 1 ? C::HSE[n + 1][2] : a == 2 ? C::HSE[n + 1][3] : C::HSE[n + 1][4];
+    const int d_raw = tile * kTwinDrones + dl;
+    const bool live = d_raw < N;
+    const int d = live ? d_raw : N - 1;
+    const int left = N - tile * kTwinDrones;
+    const int nvalid = left < kTwinDrones ? left : kTwinDrones;
+
+    if (tile != (int)blockIdx.x) wave_lds_fence();
+    {   // stage the 8 drones' inputs (one flight)
+      const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kTwinDrones * wpitch);
+      double2 *wdst = reinterpret_cast<double2 *>(sWraw);
+      const int wcnt = nvalid * wpitch / 2;
+      const double *tsrc = shared_times ? tt : tt + (size_t)tile * kTwinDrones * tpitch;
+      const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+      constexpr int UW = (kTwinDrones * wpitch / 2 + kWave - 1) / kWave;
+      constexpr int UT = (kTwinDrones * tpitch + kWave - 1) / kWave;
+      double2 vw[UW];
+      double vt[UT];
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int e = u * kWave + lane;
+        vw[u] = wsrc[e < wcnt ? e : wcnt - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int f = u * kWave + lane;
+        vt[u] = tsrc[f < tcnt ? f : tcnt - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(vw[u].x), "+v"(vw[u].y));
+#pragma unroll
+      for (int u = 0; u < UT; ++u) asm volatile("" : "+v"(vt[u]));
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int e = u * kWave + lane;
+        if (e < wcnt) wdst[e] = vw[u];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int f = u * kWave + lane;
+        if (f < tcnt) sTraw[f] = vt[u];
+      }
+    }
+    wave_lds_fence();
+    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwinDrones * M);
+
+    const int dloc = live ? dl : (N - 1 - tile * kTwinDrones);
+    const double *lw = sWraw + dloc * wpitch + a;
+    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
+    // own-coordinate accessors: side 1 walks the path backwards
+    auto Wown = [&](int i) -> double { return lw[(side ? M - i : i) * 4]; };
+    auto Town = [&](int i) -> double {
+      const int j = side ? M - 1 - i : i;
+      return lt[j + 1] - lt[j];
+    };
+
+    // ---- this side's half of the path into registers: waypoints 0..H+1, 1/T of segments 0..H ----
+    double wreg[HA + 2], xreg[HA + 1], zreg[HA][NU];
+    const double t0 = lt[0];
+    bool nonfinite = !finite64(t0);
+    bool badtime = t0 < 0.0;
+#pragma unroll
+    for (int i = 0; i <= H + 1; ++i) {
+      wreg[i] = Wown(i);
+      nonfinite |= !finite64(wreg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i <= H; ++i) {
+      double T = Town(i);
+      nonfinite |= !finite64(T);
+      badtime |= !(T > 0.0);
+      if (i == 0) {
+        T = side ? T : T - t0;   // Appendix-A quirk lives on the start side only
+        badtime |= !(T > 0.0);
+      }
+      xreg[i] = rcp64(T);
+    }
+    wave_lds_fence();   // the input stage is dead: the image and the G slots alias it
+
+    // ---- forward sweep over this side's knots (column split, see solve_kernel_quad9) ----
+    double xpp[PM], re[NU], OtG[NS], Otz[NU];   // xpp[p-1] = (1/T of the previous own segment)^p
+    {
+      double xp[PM + 1];
+      SW::powers(xreg[0], xp);
+      const double dw0 = wreg[1] - wreg[0];
+#pragma unroll
+      for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
+#pragma unroll
+      for (int n = 1; n <= NU; ++n) re[n - 1] = C::HEE[n][0] * (xp[KK - n] * dw0);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
+#pragma unroll
+      for (int r = 0; r < NU; ++r) Otz[r] = 0.0;
+    }
+    bool singular = false;
+#pragma unroll
+    for (int it = 1; it <= H; ++it) {
+      double xp[PM + 1];
+      SW::powers(xreg[it], xp);
+      const double dw = wreg[it + 1] - wreg[it];
+      double S[NS], y[NU];
+#pragma unroll
+      for (int n = 1; n <= NU; ++n) {
+#pragma unroll
+        for (int m = 1; m <= n; ++m)
+          S[sidx(n - 1, m - 1)] =
+              __builtin_fma(C::HSS[n][m], xp[KK - n - m],
+                            __builtin_fma(C::HEE[n][m], xpp[KK - n - m - 1], -OtG[sidx(n - 1, m - 1)]));
+        const double tdw = xp[KK - n] * dw;
+        y[n - 1] = __builtin_fma(-C::HSE[n][0], tdw, -(re[n - 1] + Otz[n - 1]));
+        re[n - 1] = C::HEE[n][0] * tdw;
+      }
+      double dinv[NU];
+      singular |= SW::ldl_factor(S, dinv);
+      const double pa = a == 0 ? xp[4] : a == 1 ? xp[3] : a == 2 ? xp[2] : xp[1];
+      double g[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) g[n] = ca[n] * (n == NU - 1 ? pa : pa * xp[NU - 1 - n]);
+      SW::ldl_solve(S, dinv, g);
+      SW::ldl_solve(S, dinv, y);
+      {
+        double *gs = sG + (it - 1) * kQuadSlotWords + a * 16 + blk;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) gs[r * NU * 16] = g[r];
+      }
+#pragma unroll
+      for (int r = 0; r < NU; ++r) zreg[it - 1][r] = y[r];
+#pragma unroll
+      for (int q = 0; q < NU - 1; ++q) {
+        g[q] *= xp[NU - 1 - q];
+        y[q] *= xp[NU - 1 - q];
+      }
+      double col[NU];
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        double sg = C::HSE[1][n + 1] * g[0], sz = C::HSE[1][n + 1] * y[0];
+#pragma unroll
+        for (int q = 1; q < NU; ++q) {
+          sg = __builtin_fma(C::HSE[q + 1][n + 1], g[q], sg);
+          sz = __builtin_fma(C::HSE[q + 1][n + 1], y[q], sz);
+        }
+        col[n] = sg * xp[NU - n];
+        Otz[n] = sz * xp[NU - n];
+      }
+#pragma unroll
+      for (int n = 0; n < NU; ++n) {
+        OtG[sidx(n, 0)] = quad_bcast<0>(col[n]);
+        if (n >= 1) OtG[sidx(n, 1)] = quad_bcast<1>(col[n]);
+        if (n >= 2) OtG[sidx(n, 2)] = quad_bcast<2>(col[n]);
+        if (n >= 3) OtG[sidx(n, 3)] = quad_bcast<3>(col[n]);
+      }
+#pragma unroll
+      for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
+    }
+
+    // ---- the meeting knot (solve_kernel_twist): S = (E - O^T G)_own + D (E - O^T G)_other D ----
+    double Sm[NS], um[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+      const double q = re[r] + Otz[r];
+      um[r] = -q - dsg[r] * __shfl_xor(q, 4);
+#pragma unroll
+      for (int c = 0; c <= r; ++c) {
+        const double p = __builtin_fma(C::HEE[r + 1][c + 1], xpp[KK - r - c - 3], -OtG[sidx(r, c)]);
+        Sm[sidx(r, c)] = p + (dsg[r] * dsg[c]) * __shfl_xor(p, 4);
+      }
+    }
+    {
+      double dinv[NU];
+      singular |= SW::ldl_factor(Sm, dinv);
+      SW::ldl_solve(Sm, dinv, um);
+    }
+
+    const int gsh = lane & ~7;
+    const bool f_nonfinite = ((__ballot(nonfinite) >> gsh) & 0xFFull) != 0;
+    const bool f_time = ((__ballot(badtime) >> gsh) & 0xFFull) != 0;
+    const bool f_sing = ((__ballot(singular) >> gsh) & 0xFFull) != 0;
+    const int st = f_nonfinite ? MSNAP_ST_NONFINITE : f_time ? MSNAP_ST_TIMES : f_sing ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
+    if (live && (lane & 7) == 0) status[d] = st;
+    const bool bad = st != 0;
+
+    // ---- outward back-substitution + recovery: every side owns its segments 0 .. H ----
+    const double qnan = __builtin_nan("");
+    const double zero_or_nan = bad ? qnan : 0.0;
+#pragma unroll
+    for (int i = 0; i < H + 2; ++i) wreg[i] = bad ? qnan : wreg[i];
+    double un[NU];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : um[r];
+#pragma unroll
+    for (int it = H; it >= 0; --it) {
+      double u[NU];
+      if (it >= 1) {
+        const double *gsl = sG + (it - 1) * kQuadSlotWords + blk;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+          double v = zreg[it >= 1 ? it - 1 : 0][r];
+#pragma unroll
+          for (int c = 0; c < NU; ++c) v = __builtin_fma(-gsl[(r * NU + c) * 16], un[c], v);
+          u[r] = v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NU; ++r) u[r] = zero_or_nan;
+      }
+      double ua[NU], ub[NU];
+#pragma unroll
+      for (int r = 0; r < NU; ++r) {
+        ua[r] = side ? dsg[r] * un[r] : u[r];      // state at the forward start of the piece
+        ub[r] = side ? dsg[r] * u[r] : un[r];      // state at its forward end
+      }
+      const double wa = side ? wreg[it + 1] : wreg[it];
+      const double wb = side ? wreg[it] : wreg[it + 1];
+      double c[NC];
+      recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
+      if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
+      store_twin_coalesced(sTr, coef, tile, M, it, nvalid, lane, c);
+#pragma unroll
+      for (int r = 0; r < NU; ++r) un[r] = u[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // small-batch variant (2 <= n_seg <= kTwistMaxSeg): two-sided ("twisted") sweep.
 // With few drones a launch is one wavefront's dependent chain, so the chain is halved:
 // lane = 8*drone + 4*side + axis.  Side 0 sweeps the knots from the start of the path,
@@ -1251,6 +1822,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
+constexpr int kTwinMaxSeg = 10;   // order 9, even n_seg <= 10, large batches: solve_kernel_twin9
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
@@ -1294,13 +1866,33 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
+  if (K == 5 && M >= 2 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_quad9) {
+    // order 9, large batch, even segment count: two-sided column-split kernel at two waves per SIMD
+    const int nt8 = (N + kTwinDrones - 1) / kTwinDrones;
+    int grid = ctx->n_cu * 8 * 8;
+    if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;
+    if (grid > nt8) grid = nt8;
+#define MSNAP_TWIN(MM)                                                                                          \
+  case MM:                                                                                                      \
+    hipLaunchKernelGGL((solve_kernel_twin9<MM>), dim3(grid), dim3(kWave), twin9_lds_bytes(MM), ctx->stream, wp, \
+                       t, shared, N, coef, dur, status, nt8);                                                   \
+    break;
+    switch (M) {
+      MSNAP_TWIN(2) MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
+      default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+    }
+#undef MSNAP_TWIN
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
+  }
   if (M >= 2 && M <= kRegMaxSeg2) {   // (one segment: the rolled kernel below)
     const size_t nu = K - 1;
     const size_t in_bytes = solve_input_words(M) * sizeof(double);
     const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +
                              16 * nu * nu * (size_t)(M > 2 ? M - 2 : 0) * sizeof(double);
     // persistent waves (all resident at once) so that tile k+1's inputs can be prefetched during tile k
-    const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg);
+    const bool quad9 = (K == 5 && M <= kRegMaxSeg && ctx->no_quad9 == 2);   // experiment: one-sided column split
+    const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg) || quad9;
     // Waves beyond the resident set (8 or 4 per CU) are started by the hardware as others retire, which
     // staggers the tiles' load / compute / store phases across the chip: 8x the resident set everywhere
     // (2^19..2^20 drones, order 7 M <= 10: 0.681 -> 0.647 ms, 4 tiles per wave still leave the cross-tile
@@ -1309,7 +1901,10 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     int grid = ctx->n_cu * (two_per_simd ? 8 : 4) * 8;
     if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;   // msnap_set_option: tests walk several tiles per wave
     if (grid > ntiles) grid = ntiles;
-    if (M <= kRegMaxSeg)
+    if (quad9)
+      hipLaunchKernelGGL((solve_kernel_quad9<kRegMaxSeg>), dim3(grid), dim3(kWave), quad9_lds_bytes(M), ctx->stream,
+                         wp, t, shared, N, M, coef, dur, status, ntiles);
+    else if (M <= kRegMaxSeg)
       hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
                          wp, t, shared, N, M, coef, dur, status, ntiles);
     else
