@@ -100,27 +100,6 @@ def pmc_counter(kernel: str, counter: str):
         return None
 
 
-def solve_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
-    """Which K1 variant libmsnap launches (mirror of launch_solve_k in csrc/msnap_solve.hip)."""
-    k = (order + 1) // 2
-    if 2 <= n_seg <= (24 if k == 4 else 12) and n_drones <= n_cu * 32:
-        return "msnap::solve_kernel_twist<%d, %d, %d>" % (k, (n_seg - 2) - (n_seg - 2) // 2, n_seg)
-    if n_seg <= 20:
-        return "msnap::solve_kernel_reg<%d, %d>" % (k, 10 if n_seg <= 10 else 20)
-    return "msnap::solve_kernel<%d, false>" % k
-
-
-def grid_kernel_name(n_drones: int, n_seg: int, order: int, n_cu: int = 256) -> str:
-    """Which K2 variant libmsnap launches (mirror of launch_solve_grid in csrc/msnap_grid.hip)."""
-    nc = order + 1
-    nks = (n_seg + 4) // 4
-    if (n_seg * nc + 15) // 16 <= 8 and nks <= 4:
-        return "msnap::grid_gemm_kernel<%d, %d>" % (nc, n_seg)
-    if nks <= 16:
-        return "msnap::grid_gemm_stream_kernel<%d, %d, %d>" % (nc, nks, 4 if n_drones >= 64 * n_cu else 1)
-    return solve_kernel_name(n_drones, n_seg, order, n_cu)
-
-
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -433,6 +412,7 @@ def run_formation_config(cfg, env, reps, warm):
     ctx.prepare_grid(t)      # the grid's operator, once per grid (untimed, like the context itself)
     # pass 1, stream order: per-stage times (events between the stages)
     wall, (status, hit, mh, md, pos_keep) = timed(False, ev)
+    grid_kernel = ctx.last_kernel()     # what the library launched for the shared-grid solve (msnap_last_kernel)
     # median over the repetitions: one preempted launch must not pass for a stage's time
     stage_us = [float(np.median([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)])) * 1e3 for k in range(nst)]
     # pass 2 (configs[3]): the pipeline as it is run, the mesh sweep beside the exchange and the pairwise pass
@@ -450,6 +430,7 @@ def run_formation_config(cfg, env, reps, warm):
     e1.record()
     torch.cuda.synchronize()
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
+    k1_kernel = ctx.last_kernel()
     mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial], red_dev, use_pg)
     cnt = sum_over_ranks(torch, dist, [int(status.abs().sum().item()), int(hit.sum().item()),
                                        int(mh.sum().item()) if mh is not None else 0], red_dev, use_pg)
@@ -476,11 +457,11 @@ def run_formation_config(cfg, env, reps, warm):
             if tris is not None else ""),
         "solve_failures": cnt[0], "pairwise_hits": cnt[1], "pairwise_hits_fixture": int(fix[f"cfg{cfg}_pair_hit_idx"].size),
         "stages": {
-            "solve": {"kernel": grid_kernel_name(n_max, M, order), "bound": "hbm",
+            "solve": {"kernel": grid_kernel, "bound": "hbm",
                       "frac": algorithmic_bytes(n_max, M, order) / (st["solve"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                       "note": "the swarm shares the reference's uniform time grid: fp64 MFMA GEMM against the grid's "
                               "operator (prepared once, untimed)"},
-            "solve_any_grid_k1": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm", "us": gemm,
+            "solve_any_grid_k1": {"kernel": k1_kernel, "bound": "hbm", "us": gemm,
                                   "frac": algorithmic_bytes(n_max, M, order) / (gemm * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                   "note": "same shard through the per-drone recurrence (what a swarm with per-drone "
                                           "time grids takes), outside the pipeline time"},
@@ -526,9 +507,6 @@ def run_formation_config(cfg, env, reps, warm):
     return rep
 
 
-    return rep
-
-
 def run_solve_config(env, N, M, order, reps, warm, label):
     """configs[4]: N drones x M segments sharded by drone, solve only."""
     torch, dist, device = env["torch"], env["dist"], env["device"]
@@ -540,6 +518,7 @@ def run_solve_config(env, N, M, order, reps, warm, label):
     wp, t = synth(5, N, M)                        # every rank builds the same swarm and keeps its shard
     batch = DeviceBatch(torch, ctx, wp[lo:hi], t[lo:hi], M, order, device)
     wall, dev_ms = timed_steps(torch, dist, batch, ctx, reps, warm, False, world if use_pg else 1)
+    kernel = ctx.last_kernel()
     fails = int(batch.status.abs().sum().item())
     pick = np.r_[0:min(256, hi - lo), max(0, hi - lo - 256):hi - lo]
     err, bad = oracle_parity(batch.coef, wp[lo:hi], t[lo:hi], order, pick)
@@ -554,7 +533,7 @@ def run_solve_config(env, N, M, order, reps, warm, label):
         "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling, no collective)",
         "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": {"solve": kus}, "solve_failures": cnt[0], "max_norm_rel_err_vs_oracle": mx[2],
-        "stages": {"solve": {"kernel": solve_kernel_name(n_max, M, order), "bound": "hbm",
+        "stages": {"solve": {"kernel": kernel, "bound": "hbm",
                              "algorithmic_bytes_per_launch": algorithmic_bytes(n_max, M, order),
                              "traffic": pmc_traffic(n_max, M, order)[0],
                              "frac": algorithmic_bytes(n_max, M, order) / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS}},
@@ -615,6 +594,7 @@ def main():
     batch = DeviceBatch(torch, ctx, wp, t, M, order, device)
     use_graph = not args.no_graph
     wall, dev_ms = timed_steps(torch, dist, batch, ctx, args.steps, args.warmup, use_graph, world)
+    kname = ctx.last_kernel()       # the kernel instance libmsnap chose for this launch (msnap_last_kernel)
     assert int(batch.status.abs().sum().item()) == 0, "solve reported per-drone failures"
     head_err, _ = oracle_parity(batch.coef, wp, t, order, np.arange(args.drones))
     wall_max, dev_ms_max, head_err = max_over_ranks(torch, dist, [wall, dev_ms, head_err], red_dev, use_pg)
@@ -658,6 +638,7 @@ def main():
         # (0.82 -> 0.68 ms per launch, tools/sat_ramp.py); the headline leg is warmed by its own replays
         ksat, wsat = 40, 40
         _, sat_ms = timed_steps(torch, dist, big, ctx, ksat, wsat, False, 1)
+        sat_kernel = ctx.last_kernel()
         assert int(big.status.abs().sum().item()) == 0
         # parity of what was just timed (every wave walked several tiles): both ends against the C oracle
         ends = np.r_[0:4096, nbig - 4096:nbig]
@@ -670,7 +651,7 @@ def main():
             "max_norm_rel_err_vs_oracle": sat_err, "parity_sample": "first and last 4096 drones of the timed output",
             "roofline": {"bound": "hbm", "achieved": b / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b / per / 1e9 / HBM_PEAK_GBS, "frac_of_copy_achievable": b / per / 1e9 / HBM_COPY_GBS,
-                         "kernel": solve_kernel_name(nbig, M, order),
+                         "kernel": sat_kernel,
                          "traffic": pmc_traffic(nbig, M, order)[0]},
         }
         assert sat_err <= 1e-6 and not sat_bad, f"saturated leg parity {sat_err:.3e}"
@@ -685,6 +666,7 @@ def main():
         ctx.prepare_grid(ts)
         gsmall = GridBatch(torch, ctx, wps, M, order, device)
         _, g_ms = timed_steps(torch, dist, gsmall, ctx, args.steps, args.warmup, use_graph, 1)
+        gk_small = ctx.last_kernel()
         assert int(gsmall.status.abs().sum().item()) == 0
         nbig = args.saturated_drones
         wpb = np.tile(wps, ((nbig + args.drones - 1) // args.drones, 1, 1))[:nbig]
@@ -699,7 +681,7 @@ def main():
         grid = {
             "workload": f"shared uniform time grid t_i = i*10/(M+1) (scripts/drones_pols_generator.py:44-46), "
                         f"operator prepared once, K2 fp64 MFMA GEMM per step",
-            "kernel": grid_kernel_name(args.drones, M, order),
+            "kernel": gk_small,
             "headline_shape": {"drones": args.drones, "value": args.drones / per_s, "us_per_step": per_s * 1e6,
                                "roofline_frac": bs / per_s / 1e9 / HBM_PEAK_GBS},
             "saturated": {"drones": nbig, "value": nbig / per_b, "ms_per_launch": per_b * 1e3,
@@ -724,7 +706,6 @@ def main():
         total = args.drones * world * args.steps
         per_launch_s = dev_ms_max * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes(args.drones, M, order)
-        kname = solve_kernel_name(args.drones, M, order)
         traffic = pmc_traffic(args.drones, M, order)[0]
         roof = {
             "bound": "hbm",

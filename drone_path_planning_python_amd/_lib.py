@@ -26,6 +26,7 @@ SIGNATURES = {
     "msnap_version": (_I, []),
     "msnap_strerror": (ctypes.c_char_p, [_I]),
     "msnap_last_hip_error": (ctypes.c_char_p, [_VP]),
+    "msnap_last_kernel": (ctypes.c_char_p, [_VP]),
     "msnap_create": (_I, [c_void_pp, _I, _I, _I]),
     "msnap_destroy": (None, [_VP]),
     "msnap_set_stream": (_I, [_VP, _VP]),

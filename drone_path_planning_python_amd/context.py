@@ -130,6 +130,10 @@ class Context:
         self._ck(self._lib.msnap_get_option(self._h, name.encode(), ctypes.byref(v)))
         return int(v.value)
 
+    def last_kernel(self) -> str:
+        """Kernel instance the last solve call of this context launched (msnap_last_kernel)."""
+        return self._lib.msnap_last_kernel(self._h).decode()
+
     def _coef_dur(self, coef, dur):
         """Validated host (coef [N,M,4,ncoef], dur [N,M]) and their pointers."""
         coef, pc = _host(coef, np.float64)

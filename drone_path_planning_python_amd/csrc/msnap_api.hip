@@ -6,6 +6,9 @@
 #include <cstring>
 #include <new>
 
+#include <cstdarg>
+#include <cstdio>
+
 #include "msnap_internal.h"
 
 namespace msnap {
@@ -46,15 +49,22 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_quad9", "MSNAP_NO_QUAD9"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin9", "MSNAP_NO_TWIN9"},
 };
+
+void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(ctx->last_kernel, sizeof(ctx->last_kernel), fmt, ap);
+  va_end(ap);
+}
 
 static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "solve_grid_waves")) return &ctx->solve_grid_waves;
   if (!strcmp(name, "gemm_grid_waves")) return &ctx->gemm_grid_waves;
   if (!strcmp(name, "twist_max_drones")) return &ctx->twist_max_drones;
   if (!strcmp(name, "no_twist")) return &ctx->no_twist;
-  if (!strcmp(name, "no_quad9")) return &ctx->no_quad9;
+  if (!strcmp(name, "no_twin9")) return &ctx->no_twin9;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;
   if (!strcmp(name, "own_stream_priority")) return &ctx->own_stream_priority;   // (read side; set has its own branch)
@@ -84,6 +94,8 @@ const char *msnap_strerror(int code) {
 }
 
 const char *msnap_last_hip_error(const msnap_ctx *ctx) { return ctx ? ctx->hip_err : ""; }
+
+const char *msnap_last_kernel(const msnap_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
   if (!out) return MSNAP_EINVAL;

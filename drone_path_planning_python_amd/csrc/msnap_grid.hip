@@ -369,6 +369,7 @@ static void launch_stream_nks(msnap_ctx *ctx, int N, int M, const double *wp, do
     int grid = ctx->n_cu * 16;
     if (ctx->gemm_grid_waves > 0) grid = ctx->gemm_grid_waves;
     if (grid > nrg) grid = nrg;
+    note_kernel(ctx, "msnap::grid_gemm_stream_kernel<%d, %d, %d>", NC, NKS, RT);
     hipLaunchKernelGGL((grid_gemm_stream_kernel<NC, NKS, RT>), dim3(grid, 1), dim3(kWave), 0, ctx->stream, wp, frag,
                        gdur, gst, N, M, coef, dur, status, nrg, nct, nct);
   } else {
@@ -381,6 +382,7 @@ static void launch_stream_nks(msnap_ctx *ctx, int N, int M, const double *wp, do
     slices = (nct + cts - 1) / cts;
     int grid = nrg;
     if (ctx->gemm_grid_waves > 0 && ctx->gemm_grid_waves < grid) grid = ctx->gemm_grid_waves;
+    note_kernel(ctx, "msnap::grid_gemm_stream_kernel<%d, %d, %d>", NC, NKS, RT);
     hipLaunchKernelGGL((grid_gemm_stream_kernel<NC, NKS, RT>), dim3(grid, slices), dim3(kWave), 0, ctx->stream, wp,
                        frag, gdur, gst, N, M, coef, dur, status, nrg, nct, cts);
   }
@@ -424,6 +426,7 @@ int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *co
   if (grid > nrt) grid = nrt;
 #define MSNAP_GRID_CASE(NCV, MM)                                                                       \
   case MM:                                                                                             \
+    note_kernel(ctx, "msnap::grid_gemm_kernel<%d, %d>", NCV, MM);                                      \
     hipLaunchKernelGGL((grid_gemm_kernel<NCV, MM>), dim3(grid), dim3(kWave), 0, ctx->stream, wp,       \
                        (const double *)ctx->grid_frag.p, (const double *)ctx->grid_dur.p,              \
                        (const int32_t *)ctx->grid_status.p, n_drones, coef, dur, status, nrt);         \

@@ -73,7 +73,7 @@ struct msnap_ctx {
   // launch-geometry options (msnap_set_option; the MSNAP_* environment variables of msnap.h only
   // seed them in msnap_create -- nothing on a launch path reads the environment)
   int no_twist = 0;             // "no_twist": keep small batches on the one-sided kernels (A/B timing)
-  int no_quad9 = 0;             // "no_quad9": order 9, n_seg <= 10 on solve_kernel_reg instead of the column-split kernel (A/B timing)
+  int no_twin9 = 0;             // "no_twin9": order 9 keeps solve_kernel_reg where solve_kernel_twin9 would run (A/B timing)
   int twist_max_drones = 0;     // "twist_max_drones": batches up to this size take the small-batch kernel (0: default)
   int solve_grid_waves = 0;     // "solve_grid_waves": cap on solve_kernel_reg's persistent grid (0: default)
   int gemm_grid_waves = 0;      // "gemm_grid_waves": cap on the shared-grid GEMM's persistent grid (0: default)
@@ -82,12 +82,16 @@ struct msnap_ctx {
   int collide_sample_parts = 0; // "collide_sample_parts": waves per share of the pairwise pass (0: chosen per launch)
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
   char hip_err[256] = {0};
+  char last_kernel[96] = {0};   // msnap_last_kernel: the solve kernel instance the last solve entry point launched
 };
 
 namespace msnap {
 
 int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what);
 int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes);
+
+// records the kernel instance a solve launcher chose (msnap_last_kernel; bench.py labels its rooflines with it)
+void note_kernel(msnap_ctx *ctx, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 #define MSNAP_HIP(ctx, call)                                         \
   do {                                                               \

@@ -954,19 +954,24 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
 }
 
 // ------------------------------------------------------------------------------------
-// order-9 throughput variant for n_seg <= MAXM: the matrix part of the recurrence split by
-// COLUMN over the 4 axis lanes of a drone (order 9: NU = 4 unknown derivatives per knot = 4
-// lanes).  Lane a solves column a of G_i = S_i^-1 O_i and forms column a of the Schur term
-// O_i^T G_i (plus its own axis' z_i and O_i^T z_i) instead of all four lanes carrying all 16
-// entries; the symmetric Schur block of the next knot is gathered with quad-broadcast DPP moves.
-// What a lane keeps of the previous segment is its 7 powers of 1/T (the end-side block
-// E = HEE * powers is folded into the FMAs that build S) and the 4 end-side right-hand terms.
-// All inputs of the tile go to registers at the tile top (the 10 reciprocals run side by side,
-// off the recurrence), so the input stage is dead before the first G column is stashed and the
-// LDS image is  [ pad | G slots, last knot first ]  with the output transposition image on top of
-// the pad and the LAST slot, which the backward sweep has consumed before its first store:
-// 19.8 KB per wave at n_seg = 10 and <= 256 registers -> two waves per SIMD, 8 per CU
-// (solve_kernel_reg<5,10>: 307 registers, 23.4 KB, one wave per SIMD).
+// order-9 throughput variant, two-sided AND column-split ("twin"): lane = 8*drone + 4*side + axis,
+// 8 drones per wavefront.
+//  * Two sides.  The per-lane state a solve keeps between its two sweeps (z_i, the waypoints, 1/T) is what
+//    pushes the one-sided order-9 kernel to 307 registers = one wave per SIMD; with the knots of a path
+//    shared between two sides (the merge at the meeting knot and the reversed-time bookkeeping of side 1 are
+//    those of solve_kernel_twist below) every lane keeps half of it and the dependent chain is half as long.
+//  * Column split.  Order 9 has NU = 4 unknown derivatives per knot = the 4 axis lanes of a drone: lane a
+//    solves column a of G_i = S_i^-1 O_i and forms column a of the Schur term O_i^T G_i (plus its own axis'
+//    z_i and O_i^T z_i) instead of all four lanes carrying all 16 entries; the symmetric Schur block of the
+//    next knot is gathered with quad-broadcast DPP moves, and the G columns go to LDS as they are made.
+//    What a lane carries of the previous segment is its 8 powers of 1/T (the end-side block E = HEE * powers
+//    is folded into the FMAs that build S) and 4 right-hand terms.
+//  * All inputs of the tile go to registers at the tile top (the reciprocals run side by side, off the
+//    recurrence), so the input stage is dead before the first G column is stashed and aliases the rest.
+// 256 registers without scratch and 13.6 KB of LDS -> two waves per SIMD.  One instance per even segment
+// count 4..10 (both sides own (M-2)/2 >= 1 knots and M/2 segments); odd counts keep solve_kernel_reg<5,10>.
+// (A one-sided column-split kernel was tried first: 16 drones per wave need 33 doubles of scratch at 256
+// registers and ran at 83 us against solve_kernel_reg's 75 and this kernel's 57-60 at 65 536 x 10.)
 // ------------------------------------------------------------------------------------
 template <int SRC>
 __device__ __forceinline__ double quad_bcast(double v) {   // lane SRC of the quad to all four
@@ -976,259 +981,33 @@ __device__ __forceinline__ double quad_bcast(double v) {   // lane SRC of the qu
   return __hiloint2double(hi, lo);
 }
 
-constexpr int kQuadSlotWords = 16 * 16;                                  // one knot's G: 16 entries x 16 drones
-constexpr int kQuadTrWords = 5 * kTrPitch * 2;                           // output transposition image (NC/2 = 5 rows)
-constexpr int kQuadPadWords = kQuadTrWords - kQuadSlotWords;
-inline size_t quad9_lds_bytes(int n_seg) {
-  const size_t in_words = solve_input_words(n_seg);
-  const size_t g_words = (size_t)kQuadPadWords + (size_t)(n_seg > 2 ? n_seg - 2 : 0) * kQuadSlotWords;
-  const size_t tr_words = kQuadTrWords;
-  size_t w = in_words > g_words ? in_words : g_words;
-  if (tr_words > w) w = tr_words;
-  return w * sizeof(double);
-}
+constexpr int kTwinSlotWords = 16 * 16;          // one knot's G: 16 entries x 16 (drone, side) blocks
+constexpr int kTwinTrWords = 5 * kTrPitch * 2;   // output transposition image (NC/2 = 5 rows)
+constexpr int kTwinDrones = 8;
 
-template <int MAXM>
-__global__ void __launch_bounds__(kWave, 2)
-solve_kernel_quad9(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
-                   int N, int M, double *__restrict__ coef, double *__restrict__ dur,
-                   int32_t *__restrict__ status, int ntiles) {
-  constexpr int K = 5;
-  using SW = Sweep<K>;
-  using C = HermiteConsts<K>;
-  constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
-  static_assert(NU == kAxes, "one column of the knot blocks per axis lane");
+// Output stores of the twin kernel.  The 4 axis lanes of a (drone, side) block hold the block's 320 bytes as
+// 4 x 5 pieces of 16 bytes (lane = axis, piece = coefficient pair).  Through the LDS image the pieces are
+// redistributed so that store q of lane j carries piece 4q + j of the lane's OWN block: every quad writes one
+// whole 64-byte segment per instruction (the pattern of store_quad8_at), the address is the block base plus an
+// immediate, and the only per-lane plan is where in the image the five pieces sit (set up once per tile).
+struct TwinStorePlan {
+  int ridx[5];   // double2 index into the image of the piece this lane stores with instruction q
+};
 
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-
-  const int lane0 = threadIdx.x;
-  const int wpitch = (M + 1) * 4;
-  const int tpitch = M + 1;
-  double *sWraw = lds;
-  double *sTraw = sWraw + 16 * wpitch;
-  double2 *sTr = reinterpret_cast<double2 *>(lds);
-  // G of knot i (1 <= i <= M-2) lives in slot i-1; slot M-3 (the last one written, the first one read
-  // back) sits right behind the pad, slot 0 at the far end
-  double *sGlast = lds + kQuadPadWords;
-  auto slot = [&](int s) { return sGlast + (M - 3 - s) * kQuadSlotWords; };
-
-  auto tile_valid = [&](int tl) {
-    const int left = N - tl * kDronesPerWave;
-    return left < kDronesPerWave ? left : kDronesPerWave;
-  };
-  StageRegsAsm<MAXM> pre;
-  if ((int)blockIdx.x < ntiles)
-    stage_load_asm(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), wpitch, tpitch, lane0, pre);
-  wait_vmcnt<0>();
-  constexpr int kStoresPerSeg = NC / 2;   // see solve_kernel_reg: the same cross-tile prefetch and exact wait
-
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // Everything derived from the lane index is rebuilt per tile from an opaque copy: left to the
-    // compiler, two dozen loop-invariant addresses are hoisted out of the tile loop and live -- spilled --
-    // across the whole tile, which costs more than recomputing them once per ~5 000 instructions.
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const int dl = lane >> 2;
-    const int a = lane & 3;
-    // this lane's column of the coupling block: O_i[n][a] = HSE[n+1][a+1] x^(7-n-a)
-    double ca[NU];
+__device__ __forceinline__ void twin_store_plan(int lane, TwinStorePlan &pl) {
+  const int j = lane & 3, blk4 = lane & ~3;
 #pragma unroll
-    for (int n = 0; n < NU; ++n)
-      ca[n] = a == 0 ? C::HSE[n + 1][1] : a == 1 ? C::HSE[n + 1][2] : a == 2 ? C::HSE[n + 1][3] : C::HSE[n + 1][4];
-    const int d_raw = tile * kDronesPerWave + dl;
-    const bool live = d_raw < N;
-    const int d = live ? d_raw : N - 1;
-    const int nvalid = tile_valid(tile);
-    const int next = tile + gridDim.x;
-
-    asm volatile("s_setprio 0" ::: "memory");   // tile-top marker for tools/check_prefetch_isa.py
-    wave_lds_fence();
-    stage_wait_asm<MAXM, 2 * kStoresPerSeg>(pre);
-    stage_store_asm(shared_times, nvalid, wpitch, tpitch, sWraw, sTraw, lane, pre);
-    wave_lds_fence();
-    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kDronesPerWave * M);
-    const int dloc = live ? dl : (N - 1 - tile * kDronesPerWave);
-    const double *lw = sWraw + dloc * wpitch + a;
-    const double *lt = sTraw + (shared_times ? 0 : dloc * tpitch);
-
-    // ---- the whole path into registers: waypoints, 1/T (indices past the path end replay its last
-    // entry: T = 0 there, never used) ----
-    double wreg[MAXM + 1], xreg[MAXM], zreg[MAXM > 1 ? MAXM - 1 : 1][NU];
-    const double t0 = lt[0];
-    bool nonfinite = !finite64(t0);
-    bool badtime = t0 < 0.0;
-    {
-      double treg[MAXM + 1];
-      treg[0] = t0;
-#pragma unroll
-      for (int i = 0; i <= MAXM; ++i) {
-        const int j = i <= M ? i : M;
-        wreg[i] = lw[j * 4];
-        if (i >= 1) treg[i] = lt[j];
-      }
-#pragma unroll
-      for (int i = 0; i <= MAXM; ++i) nonfinite |= !finite64(wreg[i]) | !finite64(treg[i]);
-#pragma unroll
-      for (int i = 0; i < MAXM; ++i) {
-        double T = treg[i + 1] - treg[i];
-        badtime |= (i < M) & !(T > 0.0);
-        if (i == 0) {
-          T -= t0;   // Appendix-A quirk: segment 0 has length T_0 - t0 in s - t0
-          badtime |= !(T > 0.0);
-        }
-        xreg[i] = rcp64(T);
-      }
-    }
-    wave_lds_fence();   // the input stage is dead from here on: the G slots alias it
-
-    // ---- forward sweep ----
-    double xpp[PM], re[NU], OtG[NS], Otz[NU];   // xpp[p-1] = (1/T_{i-1})^p
-    {
-      double xp[PM + 1];
-      SW::powers(xreg[0], xp);
-      const double dw0 = wreg[1] - wreg[0];
-#pragma unroll
-      for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
-#pragma unroll
-      for (int n = 1; n <= NU; ++n) re[n - 1] = C::HEE[n][0] * (xp[KK - n] * dw0);
-#pragma unroll
-      for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
-#pragma unroll
-      for (int r = 0; r < NU; ++r) Otz[r] = 0.0;
-    }
-    bool singular = false;
-#pragma unroll
-    for (int i = 1; i < MAXM; ++i) {
-      if (i < M) {
-        double xp[PM + 1];
-        SW::powers(xreg[i], xp);
-        const double dw = wreg[i + 1] - wreg[i];
-        double S[NS], y[NU];
-#pragma unroll
-        for (int n = 1; n <= NU; ++n) {
-#pragma unroll
-          for (int m = 1; m <= n; ++m)
-            S[sidx(n - 1, m - 1)] = __builtin_fma(
-                C::HSS[n][m], xp[KK - n - m],
-                __builtin_fma(C::HEE[n][m], xpp[KK - n - m - 1], -OtG[sidx(n - 1, m - 1)]));
-          const double tdw = xp[KK - n] * dw;
-          y[n - 1] = __builtin_fma(-C::HSE[n][0], tdw, -(re[n - 1] + Otz[n - 1]));
-          re[n - 1] = C::HEE[n][0] * tdw;
-        }
-        double dinv[NU];
-        singular |= SW::ldl_factor(S, dinv);
-
-        // own column of O_i, then the two solves of this lane: G column and z
-        const double pa = a == 0 ? xp[4] : a == 1 ? xp[3] : a == 2 ? xp[2] : xp[1];
-        double g[NU];
-#pragma unroll
-        for (int n = 0; n < NU; ++n) g[n] = ca[n] * (n == NU - 1 ? pa : pa * xp[NU - 1 - n]);
-        SW::ldl_solve(S, dinv, g);
-        SW::ldl_solve(S, dinv, y);
-        if (i < M - 1) {
-          double *gs = slot(i - 1) + a * 16 + dl;
-#pragma unroll
-          for (int r = 0; r < NU; ++r) gs[r * NU * 16] = g[r];
-        }
-#pragma unroll
-        for (int r = 0; r < NU; ++r) zreg[i - 1][r] = y[r];
-
-        // Schur terms for knot i+1: column a of O^T G and O^T z,
-        //   sum_q HSE[q][n] x^(9-q-n) v[q] = x^(5-n) sum_q HSE[q][n] (x^(4-q) v[q])
-#pragma unroll
-        for (int q = 0; q < NU - 1; ++q) {
-          g[q] *= xp[NU - 1 - q];
-          y[q] *= xp[NU - 1 - q];
-        }
-        double col[NU];
-#pragma unroll
-        for (int n = 0; n < NU; ++n) {
-          double sg = C::HSE[1][n + 1] * g[0], sz = C::HSE[1][n + 1] * y[0];
-#pragma unroll
-          for (int q = 1; q < NU; ++q) {
-            sg = __builtin_fma(C::HSE[q + 1][n + 1], g[q], sg);
-            sz = __builtin_fma(C::HSE[q + 1][n + 1], y[q], sz);
-          }
-          col[n] = sg * xp[NU - n];
-          Otz[n] = sz * xp[NU - n];
-        }
-#pragma unroll
-        for (int n = 0; n < NU; ++n) {
-          OtG[sidx(n, 0)] = quad_bcast<0>(col[n]);
-          if (n >= 1) OtG[sidx(n, 1)] = quad_bcast<1>(col[n]);
-          if (n >= 2) OtG[sidx(n, 2)] = quad_bcast<2>(col[n]);
-          if (n >= 3) OtG[sidx(n, 3)] = quad_bcast<3>(col[n]);
-        }
-#pragma unroll
-        for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
-      }
-    }
-
-    const int st = drone_status(nonfinite, badtime, singular);
-    if (live && a == 0) status[d] = st;
-    const bool bad = st != 0;
-
-    // ---- backward sweep + recovery (as solve_kernel_reg) ----
-    double un[NU], gq[NU][NU];
-#pragma unroll
-    for (int r = 0; r < NU; ++r) {
-      un[r] = 0.0;
-#pragma unroll
-      for (int c = 0; c < NU; ++c) gq[r][c] = 0.0;
-    }
-#pragma unroll
-    for (int i = MAXM - 1; i >= 0; --i) {
-      if (i == (MAXM >= 2 ? 1 : 0)) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int nx = next < ntiles ? next : ntiles - 1;
-        stage_load_asm(wp, tt, shared_times, nx, tile_valid(nx), wpitch, tpitch, lane, pre);
-      }
-      if (i <= 1 || i < M) {
-        double u[NU];
-#pragma unroll
-        for (int r = 0; r < NU; ++r) {
-          double v = (i >= 1) ? zreg[i >= 1 ? i - 1 : 0][r] : 0.0;
-          if (i >= 1) {
-#pragma unroll
-            for (int c = 0; c < NU; ++c) v = __builtin_fma(-gq[r][c], un[c], v);
-          }
-          u[r] = v;
-        }
-        if (i >= 2) {   // G of knot i-1 (slot i-2) for the next iteration
-          const double *gsl = slot(i - 2) + dl;
-#pragma unroll
-          for (int r = 0; r < NU; ++r)
-#pragma unroll
-            for (int c = 0; c < NU; ++c) gq[r][c] = gsl[(r * NU + c) * 16];
-        }
-        double c[NC];
-        recover_segment<K>(wreg[i], wreg[i + 1] - wreg[i], xreg[i], u, un, c);
-        if (i == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-        store_segment_coalesced<NC>(sTr, MSNAP_SEG_BASE(coef, tile, M, i, NC), MSNAP_SEG_STRIDE(M, NC), nvalid,
-                                    lane, c, bad);
-#pragma unroll
-        for (int r = 0; r < NU; ++r) un[r] = u[r];
-      }
-    }
+  for (int q = 0; q < 5; ++q) {
+    const int within = q * 4 + j;            // 16-byte piece of the block: (axis a2, pair j2)
+    const int a2 = within / 5;
+    const int j2 = within - a2 * 5;
+    pl.ridx[q] = j2 * kTrPitch + blk4 + a2;
   }
 }
 
-// ------------------------------------------------------------------------------------
-// order-9 throughput variant, two-sided AND column-split ("twin"): lane = 8*drone + 4*side + axis,
-// 8 drones per wavefront.  The per-lane state a solve must keep between its two sweeps (z_i, the
-// waypoints, 1/T) is what pushes the one-sided order-9 kernels beyond 256 registers; with the knots
-// of a path shared between two sides every lane keeps half of it, the dependent chain is half as
-// long, and with the column split (solve_kernel_quad9 above) the G columns go to LDS as they are
-// made: <= 256 registers and 13.6 KB of LDS -> two waves per SIMD.  The merge at the meeting knot and
-// the reversed-time bookkeeping of side 1 are those of solve_kernel_twist below.  One instance per
-// even segment count (both sides own (M-2)/2 knots and M/2 segments).
-// ------------------------------------------------------------------------------------
-constexpr int kTwinDrones = 8;
-
-// 16 (drone, side) blocks of 4 lanes x 10 coefficients: through the LDS image so that every store
-// instruction writes whole 64-byte segments of the blocks' 320 bytes
-__device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__restrict__ coef, int tile, int M,
-                                                     int it, int nvalid, int lane, const double (&c)[10]) {
+// `blkp`: this lane's block of the segment + (lane & 3) * 2 doubles
+__device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__restrict__ blkp, int lane,
+                                                     const TwinStorePlan &pl, const double (&c)[10]) {
   constexpr int NJ = 5;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sTr[j * kTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
@@ -1236,30 +1015,77 @@ __device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__res
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 #pragma unroll
-  for (int q = 0; q < NJ; ++q) {
-    const int s = q * kWave + lane;          // flat 16-byte slot of the wave's 16 blocks
-    const int blk = s / (4 * NJ);
-    const int within = s - blk * (4 * NJ);
-    const int a2 = within / NJ;
-    const int j2 = within - a2 * NJ;
-    const double2 v = sTr[j2 * kTrPitch + blk * 4 + a2];
-    const int drone = blk >> 1;
-    const int seg = (blk & 1) ? M - 1 - it : it;
-    // drones past the batch end replay the tile's last valid one (bitwise the same values): stored on top of it
-    const int dd = drone < nvalid ? drone : nvalid - 1;
-    double *dst = coef + ((size_t)(tile * kTwinDrones + dd) * M + seg) * (4 * 2 * NJ) + within * 2;
-    *reinterpret_cast<double2 *>(dst) = v;
-  }
+  for (int q = 0; q < NJ; ++q) *reinterpret_cast<double2 *>(blkp + q * 8) = sTr[pl.ridx[q]];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
 }
 
 inline size_t twin9_lds_bytes(int n_seg) {
   const size_t h = (size_t)(n_seg - 2) / 2;
-  const size_t g_words = h * kQuadSlotWords;                  // h knots x 16 entries x 16 (drone, side) blocks
+  const size_t g_words = h * kTwinSlotWords;                  // h knots x 16 entries x 16 (drone, side) blocks
   const size_t in_words = (size_t)kTwinDrones * (n_seg + 1) * 5;
-  const size_t body = (size_t)kQuadTrWords + g_words;
+  const size_t body = (size_t)kTwinTrWords + g_words;
   return (in_words > body ? in_words : body) * sizeof(double);
+}
+
+// cross-tile input prefetch of the twin kernel: the hand-issued loads and exact wait of solve_kernel_reg
+// (stage_load_asm / stage_wait_asm), for 8 drones per tile and a compile-time segment count
+template <int M>
+struct TwinStage {
+  static constexpr int UW = (kTwinDrones * (M + 1) * 4 / 2 + kWave - 1) / kWave;   // 16-byte loads per lane
+  static constexpr int UT = (kTwinDrones * (M + 1) + kWave - 1) / kWave;           // 8-byte loads per lane
+  u32x4 vw[UW];
+  double vt[UT];
+};
+
+template <int M>
+__device__ __forceinline__ void twin_stage_load(const double *__restrict__ wp, const double *__restrict__ tt,
+                                                int shared_times, int tile, int nvalid, int lane, TwinStage<M> &r) {
+  constexpr int wpitch = (M + 1) * 4, tpitch = M + 1;
+  const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kTwinDrones * wpitch);
+  const int wcnt = nvalid * wpitch / 2;
+  const double *tsrc = shared_times ? tt : tt + (size_t)tile * kTwinDrones * tpitch;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UW; ++u) {
+    const int e = u * kWave + lane;
+    const double2 *p = wsrc + (e < wcnt ? e : wcnt - 1);
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.vw[u]) : "v"(p) : "memory");
+  }
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UT; ++u) {
+    const int f = u * kWave + lane;
+    const double *p = tsrc + (f < tcnt ? f : tcnt - 1);
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r.vt[u]) : "v"(p) : "memory");
+  }
+}
+
+template <int M, int YOUNGER>
+__device__ __forceinline__ void twin_stage_wait(TwinStage<M> &r) {
+  wait_vmcnt<YOUNGER>();
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UW; ++u) asm volatile("" : "+v"(r.vw[u]));
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UT; ++u) asm volatile("" : "+v"(r.vt[u]));
+}
+
+template <int M>
+__device__ __forceinline__ void twin_stage_store(int shared_times, int nvalid, double *sWraw, double *sTraw, int lane,
+                                                 TwinStage<M> &r) {
+  constexpr int wpitch = (M + 1) * 4, tpitch = M + 1;
+  u32x4 *wdst = reinterpret_cast<u32x4 *>(sWraw);
+  const int wcnt = nvalid * wpitch / 2;
+  const int tcnt = shared_times ? tpitch : nvalid * tpitch;
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UW; ++u) {
+    const int e = u * kWave + lane;
+    if (e < wcnt) wdst[e] = r.vw[u];
+  }
+#pragma unroll
+  for (int u = 0; u < TwinStage<M>::UT; ++u) {
+    const int f = u * kWave + lane;
+    if (f < tcnt) sTraw[f] = r.vt[u];
+  }
 }
 
 template <int M>
@@ -1272,7 +1098,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
   using C = HermiteConsts<K>;
   constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
   static_assert(NU == kAxes, "one column of the knot blocks per axis lane");
-  static_assert(M >= 2 && (M % 2) == 0, "both sides own (M-2)/2 knots");
+  static_assert(M >= 4 && (M % 2) == 0, "both sides own (M-2)/2 >= 1 knots");
   constexpr int H = (M - 2) / 2;              // knots per side; the meeting knot is knot H+1 of both
   constexpr int HA = H > 0 ? H : 1;
 
@@ -1281,17 +1107,33 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
   const int lane0 = threadIdx.x;
   constexpr int wpitch = (M + 1) * 4;
   constexpr int tpitch = M + 1;
-  // LDS: [ transposition image | G: [knot][entry][16 blocks] ]; the input stage aliases both (dead before the first use)
+  // LDS: [ transposition image | G: [knot][row][16 blocks][column] ]; the input stage aliases both (dead before the first use)
   double *sWraw = lds;
   double *sTraw = sWraw + kTwinDrones * wpitch;
   double2 *sTr = reinterpret_cast<double2 *>(lds);
-  double *sG = lds + kQuadTrWords;
+  double *sG = lds + kTwinTrWords;
   double dsg[NU];
 #pragma unroll
   for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
 
+  auto tile_valid = [&](int tl) {
+    const int left = N - tl * kTwinDrones;
+    return left < kTwinDrones ? left : kTwinDrones;
+  };
+  // cross-tile prefetch as in solve_kernel_reg: the next tile's inputs are requested before the last two
+  // segments of the backward sweep and retired at the tile top by an exact vmcnt that leaves those two
+  // segments' 2 x kStoresPerSeg stores in flight (every instance has H >= 1, so both always run)
+  static_assert(H >= 1, "the prefetch sits in front of segments 1 and 0 of the backward sweep");
+  constexpr int kStoresPerSeg = NC / 2;
+  TwinStage<M> pre;
+  if ((int)blockIdx.x < ntiles)
+    twin_stage_load<M>(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), lane0, pre);
+  wait_vmcnt<0>();
+
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // everything derived from the lane index is rebuilt per tile from an opaque copy (see solve_kernel_quad9)
+    // Everything derived from the lane index is rebuilt per tile from an opaque copy: left to the compiler,
+    // two dozen loop-invariant addresses are hoisted out of the tile loop and live -- spilled -- across the
+    // whole tile, which costs more than recomputing them once per ~2 500 instructions.
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int a = lane & 3;
@@ -1305,45 +1147,13 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     const int d_raw = tile * kTwinDrones + dl;
     const bool live = d_raw < N;
     const int d = live ? d_raw : N - 1;
-    const int left = N - tile * kTwinDrones;
-    const int nvalid = left < kTwinDrones ? left : kTwinDrones;
+    const int nvalid = tile_valid(tile);
+    const int next = tile + gridDim.x;
 
-    if (tile != (int)blockIdx.x) wave_lds_fence();
-    {   // stage the 8 drones' inputs (one flight)
-      const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kTwinDrones * wpitch);
-      double2 *wdst = reinterpret_cast<double2 *>(sWraw);
-      const int wcnt = nvalid * wpitch / 2;
-      const double *tsrc = shared_times ? tt : tt + (size_t)tile * kTwinDrones * tpitch;
-      const int tcnt = shared_times ? tpitch : nvalid * tpitch;
-      constexpr int UW = (kTwinDrones * wpitch / 2 + kWave - 1) / kWave;
-      constexpr int UT = (kTwinDrones * tpitch + kWave - 1) / kWave;
-      double2 vw[UW];
-      double vt[UT];
-#pragma unroll
-      for (int u = 0; u < UW; ++u) {
-        const int e = u * kWave + lane;
-        vw[u] = wsrc[e < wcnt ? e : wcnt - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        const int f = u * kWave + lane;
-        vt[u] = tsrc[f < tcnt ? f : tcnt - 1];
-      }
-#pragma unroll
-      for (int u = 0; u < UW; ++u) asm volatile("" : "+v"(vw[u].x), "+v"(vw[u].y));
-#pragma unroll
-      for (int u = 0; u < UT; ++u) asm volatile("" : "+v"(vt[u]));
-#pragma unroll
-      for (int u = 0; u < UW; ++u) {
-        const int e = u * kWave + lane;
-        if (e < wcnt) wdst[e] = vw[u];
-      }
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        const int f = u * kWave + lane;
-        if (f < tcnt) sTraw[f] = vt[u];
-      }
-    }
+    asm volatile("s_setprio 0" ::: "memory");   // tile-top marker for tools/check_prefetch_isa.py
+    wave_lds_fence();   // the previous tile's LDS reads are done (in-order LDS, one wave)
+    twin_stage_wait<M, 2 * kStoresPerSeg>(pre);
+    twin_stage_store<M>(shared_times, nvalid, sWraw, sTraw, lane, pre);
     wave_lds_fence();
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwinDrones * M);
 
@@ -1380,8 +1190,11 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     }
     wave_lds_fence();   // the input stage is dead: the image and the G slots alias it
 
-    // ---- forward sweep over this side's knots (column split, see solve_kernel_quad9) ----
-    double xpp[PM], re[NU], OtG[NS], Otz[NU];   // xpp[p-1] = (1/T of the previous own segment)^p
+    // ---- forward sweep over this side's knots (column split) ----
+    // carried from knot to knot: the powers of the previous own segment's 1/T (xpp[p-1] = x^p; the end-side block
+    // E = HEE * powers is folded into the FMAs that build S), rz = that segment's end-side right-hand term +
+    // O^T z of the previous knot, and the Schur block O^T G
+    double xpp[PM], rz[NU], OtG[NS];
     {
       double xp[PM + 1];
       SW::powers(xreg[0], xp);
@@ -1389,11 +1202,9 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
 #pragma unroll
       for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
 #pragma unroll
-      for (int n = 1; n <= NU; ++n) re[n - 1] = C::HEE[n][0] * (xp[KK - n] * dw0);
+      for (int n = 1; n <= NU; ++n) rz[n - 1] = C::HEE[n][0] * (xp[KK - n] * dw0);
 #pragma unroll
       for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
-#pragma unroll
-      for (int r = 0; r < NU; ++r) Otz[r] = 0.0;
     }
     bool singular = false;
 #pragma unroll
@@ -1403,15 +1214,17 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       const double dw = wreg[it + 1] - wreg[it];
       double S[NS], y[NU];
 #pragma unroll
-      for (int n = 1; n <= NU; ++n) {
+      for (int n = 1; n <= NU; ++n)
 #pragma unroll
         for (int m = 1; m <= n; ++m)
           S[sidx(n - 1, m - 1)] =
               __builtin_fma(C::HSS[n][m], xp[KK - n - m],
                             __builtin_fma(C::HEE[n][m], xpp[KK - n - m - 1], -OtG[sidx(n - 1, m - 1)]));
+#pragma unroll
+      for (int n = 1; n <= NU; ++n) {
         const double tdw = xp[KK - n] * dw;
-        y[n - 1] = __builtin_fma(-C::HSE[n][0], tdw, -(re[n - 1] + Otz[n - 1]));
-        re[n - 1] = C::HEE[n][0] * tdw;
+        y[n - 1] = __builtin_fma(-C::HSE[n][0], tdw, -rz[n - 1]);
+        rz[n - 1] = C::HEE[n][0] * tdw;
       }
       double dinv[NU];
       singular |= SW::ldl_factor(S, dinv);
@@ -1422,9 +1235,10 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       SW::ldl_solve(S, dinv, g);
       SW::ldl_solve(S, dinv, y);
       {
-        double *gs = sG + (it - 1) * kQuadSlotWords + a * 16 + blk;
+        // [knot][row r][block][column a]: the 64 lanes of a store write 64 consecutive doubles
+        double *gs = sG + (it - 1) * kTwinSlotWords + lane;
 #pragma unroll
-        for (int r = 0; r < NU; ++r) gs[r * NU * 16] = g[r];
+        for (int r = 0; r < NU; ++r) gs[r * kWave] = g[r];
       }
 #pragma unroll
       for (int r = 0; r < NU; ++r) zreg[it - 1][r] = y[r];
@@ -1443,7 +1257,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
           sz = __builtin_fma(C::HSE[q + 1][n + 1], y[q], sz);
         }
         col[n] = sg * xp[NU - n];
-        Otz[n] = sz * xp[NU - n];
+        rz[n] = __builtin_fma(sz, xp[NU - n], rz[n]);
       }
 #pragma unroll
       for (int n = 0; n < NU; ++n) {
@@ -1460,7 +1274,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     double Sm[NS], um[NU];
 #pragma unroll
     for (int r = 0; r < NU; ++r) {
-      const double q = re[r] + Otz[r];
+      const double q = rz[r];
       um[r] = -q - dsg[r] * __shfl_xor(q, 4);
 #pragma unroll
       for (int c = 0; c <= r; ++c) {
@@ -1485,6 +1299,11 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     // ---- outward back-substitution + recovery: every side owns its segments 0 .. H ----
     const double qnan = __builtin_nan("");
     const double zero_or_nan = bad ? qnan : 0.0;
+    // drones past the batch end replay the tile's last valid one (bitwise the same values) and store on top of it
+    TwinStorePlan plan;
+    twin_store_plan(lane, plan);
+    double *blkp = coef + ((size_t)d * M + (side ? M - 1 - H : H)) * (4 * NC) + a * 2;
+    const int blkstep = side ? 4 * NC : -(4 * NC);   // side 0 walks its segments down, side 1 up
 #pragma unroll
     for (int i = 0; i < H + 2; ++i) wreg[i] = bad ? qnan : wreg[i];
     double un[NU];
@@ -1492,14 +1311,24 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : um[r];
 #pragma unroll
     for (int it = H; it >= 0; --it) {
+      if (it == 1) {
+        // with two segments left most of this tile's registers are dead: the next tile's inputs start now
+        // (unconditional, clamped to the last tile, at a static point of the unrolled loop)
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = next < ntiles ? next : ntiles - 1;
+        twin_stage_load<M>(wp, tt, shared_times, nx, tile_valid(nx), lane, pre);
+      }
       double u[NU];
       if (it >= 1) {
-        const double *gsl = sG + (it - 1) * kQuadSlotWords + blk;
+        const double2 *gsl = reinterpret_cast<const double2 *>(sG + (it - 1) * kTwinSlotWords + blk * NU);
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
+          const double2 g01 = gsl[r * (kWave / 2)], g23 = gsl[r * (kWave / 2) + 1];
           double v = zreg[it >= 1 ? it - 1 : 0][r];
-#pragma unroll
-          for (int c = 0; c < NU; ++c) v = __builtin_fma(-gsl[(r * NU + c) * 16], un[c], v);
+          v = __builtin_fma(-g01.x, un[0], v);
+          v = __builtin_fma(-g01.y, un[1], v);
+          v = __builtin_fma(-g23.x, un[2], v);
+          v = __builtin_fma(-g23.y, un[3], v);
           u[r] = v;
         }
       } else {
@@ -1517,7 +1346,8 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       double c[NC];
       recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
       if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-      store_twin_coalesced(sTr, coef, tile, M, it, nvalid, lane, c);
+      store_twin_coalesced(sTr, blkp, lane, plan, c);
+      blkp += blkstep;
 #pragma unroll
       for (int r = 0; r < NU; ++r) un[r] = u[r];
     }
@@ -1841,6 +1671,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     const size_t lds_bytes = ((size_t)kTwistDrones * (M + 1) * 5 + (size_t)64 * (K - 1) * nR) * sizeof(double);
 #define MSNAP_TWIST_EXACT(MM)                                                                          \
   case MM:                                                                                             \
+    note_kernel(ctx, "msnap::solve_kernel_twist<%d, %d, %d>", K, (MM - 2) - (MM - 2) / 2, MM);         \
     hipLaunchKernelGGL((solve_kernel_twist<K, (MM - 2) - (MM - 2) / 2, MM>), dim3(nt8), dim3(kWave),   \
                        lds_bytes, ctx->stream, wp, t, shared, N, coef, dur, status, nt8);             \
     break;
@@ -1866,7 +1697,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
-  if (K == 5 && M >= 2 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_quad9) {
+  if (K == 5 && M >= 4 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_twin9) {
     // order 9, large batch, even segment count: two-sided column-split kernel at two waves per SIMD
     const int nt8 = (N + kTwinDrones - 1) / kTwinDrones;
     int grid = ctx->n_cu * 8 * 8;
@@ -1874,11 +1705,12 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     if (grid > nt8) grid = nt8;
 #define MSNAP_TWIN(MM)                                                                                          \
   case MM:                                                                                                      \
+    note_kernel(ctx, "msnap::solve_kernel_twin9<%d>", MM);                                                      \
     hipLaunchKernelGGL((solve_kernel_twin9<MM>), dim3(grid), dim3(kWave), twin9_lds_bytes(MM), ctx->stream, wp, \
                        t, shared, N, coef, dur, status, nt8);                                                   \
     break;
     switch (M) {
-      MSNAP_TWIN(2) MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
+      MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
       default: return MSNAP_EINVAL;   // unreachable: the range is checked above
     }
 #undef MSNAP_TWIN
@@ -1891,8 +1723,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     const size_t lds_bytes = (in_bytes > tr_bytes ? in_bytes : tr_bytes) +
                              16 * nu * nu * (size_t)(M > 2 ? M - 2 : 0) * sizeof(double);
     // persistent waves (all resident at once) so that tile k+1's inputs can be prefetched during tile k
-    const bool quad9 = (K == 5 && M <= kRegMaxSeg && ctx->no_quad9 == 2);   // experiment: one-sided column split
-    const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg) || quad9;
+    const bool two_per_simd = (K <= 4 && M <= kRegMaxSeg);
     // Waves beyond the resident set (8 or 4 per CU) are started by the hardware as others retire, which
     // staggers the tiles' load / compute / store phases across the chip: 8x the resident set everywhere
     // (2^19..2^20 drones, order 7 M <= 10: 0.681 -> 0.647 ms, 4 tiles per wave still leave the cross-tile
@@ -1901,10 +1732,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     int grid = ctx->n_cu * (two_per_simd ? 8 : 4) * 8;
     if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;   // msnap_set_option: tests walk several tiles per wave
     if (grid > ntiles) grid = ntiles;
-    if (quad9)
-      hipLaunchKernelGGL((solve_kernel_quad9<kRegMaxSeg>), dim3(grid), dim3(kWave), quad9_lds_bytes(M), ctx->stream,
-                         wp, t, shared, N, M, coef, dur, status, ntiles);
-    else if (M <= kRegMaxSeg)
+    note_kernel(ctx, "msnap::solve_kernel_reg<%d, %d>", K, M <= kRegMaxSeg ? kRegMaxSeg : kRegMaxSeg2);
+    if (M <= kRegMaxSeg)
       hipLaunchKernelGGL((solve_kernel_reg<K, kRegMaxSeg>), dim3(grid), dim3(kWave), lds_bytes, ctx->stream,
                          wp, t, shared, N, M, coef, dur, status, ntiles);
     else
@@ -1916,6 +1745,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   const size_t words = solve_scratch_words(K, M);
   const size_t lds_bytes = tr_bytes + (words + solve_input_words(M)) * sizeof(double);
   const size_t bytes = words * sizeof(double);
+  note_kernel(ctx, "msnap::solve_kernel<%d, %s>", K, lds_bytes <= kMaxLdsBytes ? "false" : "true");
   if (lds_bytes <= kMaxLdsBytes) {
     hipLaunchKernelGGL((solve_kernel<K, false>), dim3(ntiles), dim3(kWave), lds_bytes, ctx->stream, wp, t,
                        shared, N, M, coef, dur, status, (double *)nullptr, ntiles);

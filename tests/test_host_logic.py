@@ -185,12 +185,6 @@ def test_bench_accounting_helpers():
     assert bench.algorithmic_bytes(1, 20, 7) == 6120
     assert bench.algorithmic_bytes(1, 10, 9) == 3720
     assert bench.algorithmic_bytes(256, 10, 7) == 788480
-    assert bench.solve_kernel_name(256, 10, 7) == "msnap::solve_kernel_twist<4, 4, 10>"
-    assert bench.solve_kernel_name(4096, 20, 7) == "msnap::solve_kernel_twist<4, 9, 20>"
-    assert bench.solve_kernel_name(1 << 20, 10, 7) == "msnap::solve_kernel_reg<4, 10>"
-    assert bench.solve_kernel_name(1 << 20, 20, 7) == "msnap::solve_kernel_reg<4, 20>"
-    assert bench.solve_kernel_name(65536, 10, 9) == "msnap::solve_kernel_reg<5, 10>"
-    assert bench.solve_kernel_name(64, 49, 7) == "msnap::solve_kernel<4, false>"
     assert bench.METRIC.startswith("minimum-snap trajectories/sec")
     tr, kn = bench.pmc_traffic(256, 10, 7)
     assert tr is None or tr > 788480 * 0.9

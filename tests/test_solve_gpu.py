@@ -736,3 +736,38 @@ def test_two_threads_two_contexts_and_one_shared_context(golden):
         for th in threads:
             th.join()
     assert not errors, errors
+
+
+def test_last_kernel_reports_the_launched_instance():
+    """msnap_last_kernel: the library names the kernel instance a solve launched (bench.py labels its
+    rooflines with it instead of mirroring the launcher's thresholds)."""
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    with Context(order=7, max_segments=64) as ctx:
+        assert ctx.last_kernel() == ""
+        for n, m, want in [(256, 10, "msnap::solve_kernel_twist<4, 4, 10>"),
+                           (300, 20, "msnap::solve_kernel_twist<4, 9, 20>"),
+                           (64, 49, "msnap::solve_kernel<4, false>")]:
+            wp, t = swarm(77, n, m)
+            ctx.solve_batch(wp, t)
+            assert ctx.last_kernel() == want
+        ctx.set_option("no_twist", 1)
+        wp, t = swarm(78, 300, 10)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 10>"
+        wp, t = swarm(79, 40, 10, shared_times=True)
+        ctx.prepare_grid(t)
+        ctx.solve_grid(wp)
+        assert ctx.last_kernel() == "msnap::grid_gemm_kernel<8, 10>"
+    with Context(order=9, max_segments=64) as ctx:
+        ctx.set_option("no_twist", 1)
+        for m, want in [(10, "msnap::solve_kernel_twin9<10>"), (6, "msnap::solve_kernel_twin9<6>"),
+                        (7, "msnap::solve_kernel_reg<5, 10>"), (2, "msnap::solve_kernel_reg<5, 10>"),
+                        (16, "msnap::solve_kernel_reg<5, 20>")]:
+            wp, t = swarm(80 + m, 100, m)
+            ctx.solve_batch(wp, t)
+            assert ctx.last_kernel() == want
+        ctx.set_option("no_twin9", 1)
+        wp, t = swarm(90, 100, 10)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<5, 10>"

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Build-time check of the hand-counted cross-tile prefetch of solve_kernel_reg (csrc/msnap_solve.hip).
+"""Build-time check of the hand-counted cross-tile prefetch of solve_kernel_reg and solve_kernel_twin9
+(csrc/msnap_solve.hip).
 
 The persistent solve issues the next tile's input loads from inline asm during the last two
 segments of a tile and retires them with `s_waitcnt vmcnt(N)`, N <= the store instructions issued
 after them (the compiler does not see asm loads, so nothing else would wait for them, and a wait
 that is too loose would read registers whose loads have not landed).  This script disassembles the
-gfx950 code object inside msnap_solve.o and checks, for every solve_kernel_reg instance:
+gfx950 code object inside msnap_solve.o and checks, for every solve_kernel_reg / solve_kernel_twin9 instance:
   1. the in-loop prefetch burst exists (UW dwordx4 + UT dwordx2 loads back to back);
   2. the kernel holds exactly MAXM x kStoresPerSeg coefficient stores (global_store_dwordx4: 4 per
      segment at order 7, 5 at order 9): the compiler neither merged, split nor dropped one;
@@ -48,8 +49,17 @@ def regs(tok):
     return out
 
 
+def kernel_shape(name):
+    """(K, segments whose stores the instance holds) from the mangled name."""
+    m = re.search(r"solve_kernel_regILi(\d+)ELi(\d+)E", name)
+    if m:
+        return int(m.group(1)), int(m.group(2))          # K = 4 (order 7) or 5 (order 9), MAXM segments
+    m = re.search(r"solve_kernel_twin9ILi(\d+)E", name)
+    return 5, int(m.group(1)) // 2                        # order 9, every side stores its M/2 segments
+
+
 def check_kernel(name, body):
-    k = int(re.search(r"ILi(\d+)ELi(\d+)E", name).group(1))          # K = 4 (order 7) or 5 (order 9)
+    k, segs = kernel_shape(name)
     stores_per_seg = 4 if k == 4 else 5
     ins = []
     for text, addr, target in body:
@@ -65,7 +75,7 @@ def check_kernel(name, body):
                 if ins[j][0].startswith("global_load_dwordx"):
                     loads.append(j)
                 j += 1
-            if len(loads) >= 4:
+            if len(loads) >= 3:
                 bursts.append(loads)
                 i = loads[-1] + 1
                 continue
@@ -76,10 +86,9 @@ def check_kernel(name, body):
     dest = set()
     for j in loads:
         dest |= regs(ins[j][1].split(",")[0])
-    maxm = int(re.search(r"ILi(\d+)ELi(\d+)E", name).group(2))
     total_stores = sum(1 for op, _, _, _ in ins if op == "global_store_dwordx4")
-    if total_stores != maxm * stores_per_seg:
-        return f"{name}: {total_stores} coefficient stores in the kernel, expected {maxm} x {stores_per_seg}"
+    if total_stores != segs * stores_per_seg:
+        return f"{name}: {total_stores} coefficient stores in the kernel, expected {segs} x {stores_per_seg}"
     want = 2 * stores_per_seg
     # control-flow walks (both branch outcomes, whatever the block layout):
     #   A. from the end of the burst to the tile-top marker (`s_setprio 0`, issued once per tile in front of
@@ -166,7 +175,7 @@ def main():
     text = disassemble(obj)
     kernels, cur = {}, None
     for ln in text.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(_ZN5msnap16solve_kernel_reg\w+)>:", ln)
+        m = re.match(r"^[0-9a-f]+ <(_ZN5msnap(?:16solve_kernel_reg|18solve_kernel_twin9)\w+)>:", ln)
         if m:
             cur = m.group(1)
             kernels[cur] = []
@@ -181,15 +190,15 @@ def main():
             t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", ln)
             base = kernels[cur][0][1] if kernels[cur] else int(m.group(1), 16)
             kernels[cur].append((text, int(m.group(1), 16), base + int(t.group(1), 16) if t else None))
-    if len(kernels) != 4:
-        print(f"check_prefetch_isa: expected 4 solve_kernel_reg instances, found {len(kernels)}")
+    if len(kernels) != 8:
+        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 4 solve_kernel_twin9 instances, found {len(kernels)}")
         return 1
     res = {n: check_kernel(n, b) for n, b in sorted(kernels.items())}
     bad = [e for e in res.values() if e]
     for e in bad:
         print("check_prefetch_isa:", e)
     if not bad:
-        print(f"check_prefetch_isa: {len(kernels)} solve_kernel_reg instances ok (store counts, waits, and on every "
+        print(f"check_prefetch_isa: {len(kernels)} persistent solve instances ok (store counts, waits, and on every "
               f"path from the prefetch to its wait: stores counted, no early reads)")
     return 1 if bad else 0
 

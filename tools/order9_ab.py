@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Order-9 large-batch solve, A/B over the kernel choice ("no_quad9": 0 two-sided column-split kernel,
-1 solve_kernel_reg<5,10>, 2 one-sided column-split experiment) and the persistent grid.
+"""Order-9 large-batch solve, A/B over the kernel choice ("no_twin9": 0 two-sided column-split kernel,
+1 solve_kernel_reg<5,10>) and the persistent grid.
    python tools/order9_ab.py [drones=65536] [segments=10]"""
 import os
 import sys
@@ -29,9 +29,9 @@ ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ctx.set_option("no_twist", 1)
 bytes_ = N * (8 * 5 * (M + 1) + 8 * M * (1 + 4 * (order + 1)))
 ref = None
-for mode in (1, 0, 2, 0, 1):
-    ctx.set_option("no_quad9", mode)
-    for waves in (0, 2048, 4096, 8192):
+for mode in (0, 1, 0):
+    ctx.set_option("no_twin9", mode)
+    for waves in (0, 2048, 4096):
         ctx.set_option("solve_grid_waves", waves)
         for _ in range(40):
             ctx.solve_batch_device(N, M, twp, tt, False, coef, dur, st)
@@ -47,6 +47,6 @@ for mode in (1, 0, 2, 0, 1):
         if ref is None:
             ref = c.copy()
         err = float((np.abs(c - ref).max(axis=(1, 3)) / np.abs(ref).max(axis=(1, 3))).max())
-        print(f"no_quad9={mode} {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak; "
+        print(f"no_twin9={mode} {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak; "
               f"vs solve_kernel_reg {err:.2e}; status ok {bool((st == 0).all())}", flush=True)
 ctx.close()
