@@ -57,6 +57,11 @@ SIGNATURES = {
     "msnap_snap_cost_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_formation_collide": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_collide_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
+    "msnap_formation_part_bytes": (ctypes.c_size_t, [_I]),
+    "msnap_formation_collide_part": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
+    "msnap_formation_collide_part_device": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
+    "msnap_formation_collide_finish": (_I, [_VP, _I, _I, _VP, _I, _I, _D, _VP, _VP, _VP]),
+    "msnap_formation_collide_finish_device": (_I, [_VP, _I, _I, _VP, _I, _I, _D, _VP, _VP, _VP]),
     "msnap_mesh_sweep": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
     "msnap_mesh_sweep_device": (_I, [_VP, _I, _I, _VP, _I, _VP, _D, _VP, _VP]),
     "msnap_mesh_validity": (_I, [_VP, _I, _VP, _I, _VP, _I, _VP, _VP]),

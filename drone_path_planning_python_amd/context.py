@@ -355,6 +355,58 @@ class Context:
                 self._h, int(n_rows), int(row_offset), int(n_cols), int(n_samples), _ptr(pos_rows),
                 _ptr(pos_cols), float(radius), _ptr(min_dist), _ptr(partner), _ptr(hit)))
 
+    # ---- the pairwise pass in parts: every unordered pair on exactly one rank (include/msnap.h) ----
+    def formation_part_bytes(self, n_drones: int) -> int:
+        return int(self._lib.msnap_formation_part_bytes(int(n_drones)))
+
+    def formation_collide_part(self, pos_all, part: int, n_parts: int):
+        """One rank's part of the pass over the whole swarm `pos_all` [N,S,3]: a uint8 block of
+        formation_part_bytes(N) bytes (squared minima [N] float64, then partners [N] int32)."""
+        pa, ppa = _host(pos_all, np.float64)
+        if pa.ndim != 3 or pa.shape[2] != 3:
+            raise ValueError("pos_all must be [N, S, 3]")
+        N, S, _ = pa.shape
+        out = np.empty((self.formation_part_bytes(N),), dtype=np.uint8)
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_part(self._h, N, S, ppa, int(part), int(n_parts),
+                                                            out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    @staticmethod
+    def split_part(block, n_drones: int):
+        """(squared minima [N] float64, partners [N] int32) views of one part block."""
+        b = np.ascontiguousarray(block, dtype=np.uint8)
+        return b[:8 * n_drones].view(np.float64), b[8 * n_drones:12 * n_drones].view(np.int32)
+
+    def formation_collide_finish(self, parts, n_drones: int, radius: float, row_offset: int = 0, n_rows=None):
+        """Fold the parts (uint8 [P, formation_part_bytes(N)]) for the rows [row_offset, row_offset + n_rows)."""
+        pb, ppb = _host(parts, np.uint8)
+        stride = self.formation_part_bytes(n_drones)
+        if pb.ndim != 2 or pb.shape[1] != stride:
+            raise ValueError("parts must be [P, formation_part_bytes(N)] uint8")
+        n_rows = n_drones - row_offset if n_rows is None else int(n_rows)
+        md = np.empty((n_rows,), dtype=np.float64)
+        partner = np.empty((n_rows,), dtype=np.int32)
+        hit = np.empty((n_rows,), dtype=np.int32)
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_finish(
+                self._h, int(n_drones), pb.shape[0], ppb, int(row_offset), n_rows, float(radius),
+                md.ctypes.data_as(ctypes.c_void_p), partner.ctypes.data_as(ctypes.c_void_p),
+                hit.ctypes.data_as(ctypes.c_void_p)))
+        return md, partner, hit.astype(bool)
+
+    def formation_collide_part_device(self, n_drones, n_samples, pos_all, part, n_parts, part_out):
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_part_device(
+                self._h, int(n_drones), int(n_samples), _ptr(pos_all), int(part), int(n_parts), _ptr(part_out)))
+
+    def formation_collide_finish_device(self, n_drones, n_parts, parts, row_offset, n_rows, radius, min_dist,
+                                        partner, hit):
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_finish_device(
+                self._h, int(n_drones), int(n_parts), _ptr(parts), int(row_offset), int(n_rows), float(radius),
+                _ptr(min_dist), _ptr(partner), _ptr(hit)))
+
     def mesh_sweep(self, pos, tris, radius: float):
         p, pp = _host(pos, np.float64)
         tr, ptr_ = _host(tris, np.float64)

@@ -698,6 +698,77 @@ int msnap_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_co
   return MSNAP_OK;
 }
 
+// ------------------------------------------------------------------ formation pass in parts (one per rank)
+size_t msnap_formation_part_bytes(int n_drones) {
+  if (n_drones < 0) return 0;
+  return ((size_t)n_drones * (sizeof(double) + sizeof(int32_t)) + 7) & ~(size_t)7;
+}
+
+int msnap_formation_collide_part_device(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all, int part,
+                                        int n_parts, void *part_out) {
+  if (!ctx || n_drones < 0 || n_samples < 1 || n_parts < 1 || part < 0 || part >= n_parts) return MSNAP_EINVAL;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!pos_all || !part_out || ((uintptr_t)part_out & 7)) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_formation_collide_part(ctx, n_drones, n_samples, pos_all, part, n_parts, (double *)part_out,
+                                       (int32_t *)((unsigned char *)part_out + (size_t)n_drones * sizeof(double)));
+}
+
+int msnap_formation_collide_finish_device(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts, int row_offset,
+                                          int n_rows, double radius, double *min_dist, int32_t *partner, int32_t *hit) {
+  if (!ctx || n_drones < 0 || n_parts < 1 || row_offset < 0 || n_rows < 0 || !(radius >= 0.0)) return MSNAP_EINVAL;
+  if ((long long)row_offset + n_rows > n_drones) return MSNAP_EINVAL;
+  if (n_rows == 0) return MSNAP_OK;
+  if (!parts || !min_dist || !partner || !hit || ((uintptr_t)parts & 7)) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_formation_collide_finish(ctx, n_drones, n_parts, parts, msnap_formation_part_bytes(n_drones),
+                                         row_offset, n_rows, radius, min_dist, partner, hit);
+}
+
+int msnap_formation_collide_part(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all, int part,
+                                 int n_parts, void *part_out) {
+  if (!ctx || n_drones < 0 || n_samples < 1 || n_parts < 1 || part < 0 || part >= n_parts) return MSNAP_EINVAL;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!pos_all || !part_out) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_pos = (size_t)n_drones * n_samples * 3 * 8, b_out = msnap_formation_part_bytes(n_drones);
+  int rc;
+  if ((rc = ensure(ctx, ctx->stage[1], b_pos + 8))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[2], b_out))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, pos_all, b_pos, hipMemcpyHostToDevice, ctx->stream));
+  rc = msnap_formation_collide_part_device(ctx, n_drones, n_samples, (const double *)ctx->stage[1].p, part, n_parts,
+                                           ctx->stage[2].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(part_out, ctx->stage[2].p, b_out, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
+int msnap_formation_collide_finish(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts, int row_offset,
+                                   int n_rows, double radius, double *min_dist, int32_t *partner, int32_t *hit) {
+  if (!ctx || n_drones < 0 || n_parts < 1 || row_offset < 0 || n_rows < 0 || !(radius >= 0.0)) return MSNAP_EINVAL;
+  if ((long long)row_offset + n_rows > n_drones) return MSNAP_EINVAL;
+  if (n_rows == 0) return MSNAP_OK;
+  if (!parts || !min_dist || !partner || !hit) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b_in = msnap_formation_part_bytes(n_drones) * (size_t)n_parts;
+  int rc;
+  if ((rc = ensure(ctx, ctx->stage[1], b_in + 8))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[2], (size_t)n_rows * 8))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[3], (size_t)n_rows * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->stage[4], (size_t)n_rows * 4))) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, parts, b_in, hipMemcpyHostToDevice, ctx->stream));
+  rc = msnap_formation_collide_finish_device(ctx, n_drones, n_parts, ctx->stage[1].p, row_offset, n_rows, radius,
+                                             (double *)ctx->stage[2].p, (int32_t *)ctx->stage[3].p,
+                                             (int32_t *)ctx->stage[4].p);
+  if (rc) return rc;
+  MSNAP_HIP(ctx, hipMemcpyAsync(min_dist, ctx->stage[2].p, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(partner, ctx->stage[3].p, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipMemcpyAsync(hit, ctx->stage[4].p, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+  MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MSNAP_OK;
+}
+
 // ------------------------------------------------------------------ mesh sweep
 int msnap_mesh_sweep_device(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos, int n_tris,
                             const double *tris, double radius, double *min_dist, int32_t *hit) {

@@ -529,6 +529,13 @@ struct CollideGeom {
   long long split;          // first unit of the tail shares (a multiple of upw)
   int sparts;               // sample parts: a share of the line is taken by `sparts` waves, each a range of chunks
   long long total;          // units of the launch
+  // One rank's part of a pass over the whole swarm (msnap_formation_collide_part): the launch covers the shares
+  // [w_lo, w_hi) of the global line, which touch the row blocks I_lo .. I_hi; the transposed row image and the
+  // partial buffers are indexed relative to them, and the merge writes the squared minimum of EVERY drone
+  // (+inf / -1 where this part met none of its pairs) instead of distances.  Whole launches: 0, shares, 0, n_rb - 1.
+  long long w_lo, w_hi;
+  int I_lo, I_hi;
+  int part;
 };
 
 // units of the row blocks before I: without the own-range shortcut every row block meets all Cn columns;
@@ -755,7 +762,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       ci = take ? oi : ci;
     }
     if (part == 0 && c < ncols) {
-      const size_t slot = ((size_t)I * g.sparts + h) * g.R + (size_t)(cj + c - g.os);
+      const size_t slot = ((size_t)(I - g.I_lo) * g.sparts + h) * g.R + (size_t)(cj + c - g.os);
       cpart_d2[slot] = cm;
       cpart_i[slot] = (cm == INFINITY) ? -1 : g.ro + I * kRowBlock + ci;
     }
@@ -766,10 +773,19 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
 
 // The rows of a call as [sample][xyz][row] (row pitch Rp; the rows behind R replay row R - 1): 64 x 64
 // tiles through LDS, read along a drone's samples and written along the rows.
+// Rows of workgroups behind the `ny` of the transposition mark the column-side partner slots of a part launch
+// as empty (-1): a part covers its first and last row block only partly, and the merge skips empty slots.
 __global__ void __launch_bounds__(256)
-collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t) {
+collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t, int ny,
+                         int32_t *__restrict__ fill, size_t fill_n) {
   constexpr int TE = 32;      // elements of a drone per tile (x 64 rows): 2.4 workgroups per CU at 4096 x 91
   __shared__ double tile[64][TE + 1];
+  if ((int)blockIdx.y >= ny) {
+    const size_t stride = (size_t)(gridDim.y - ny) * gridDim.x * 256;
+    for (size_t i = ((size_t)(blockIdx.y - ny) * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < fill_n; i += stride)
+      fill[i] = -1;
+    return;
+  }
   const int r0 = blockIdx.x * 64, e0 = blockIdx.y * TE;
   {
     const int tx = threadIdx.x & (TE - 1), ty = threadIdx.x / TE;
@@ -796,9 +812,10 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
-  const int w = blockIdx.x / g.sparts, h = blockIdx.x - w * g.sparts;
+  const int wl = blockIdx.x / g.sparts, h = blockIdx.x - wl * g.sparts;
+  const long long w = g.w_lo + wl;
   long long u = collide_share_begin(g, w);
-  const long long u_end = collide_share_begin(g, (long long)w + 1);
+  const long long u_end = collide_share_begin(g, w + 1);
   if (u >= u_end) return;
   // the row block the share starts in
   int I = 0;
@@ -820,7 +837,7 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
       rs.best[rr] = INFINITY;
       rs.bestj[rr] = -1;
     }
-    const double *prowT = prow_t + (size_t)I * kRowBlock;
+    const double *prowT = prow_t + (size_t)(I - g.I_lo) * kRowBlock;
     for (int ux = ua; ux < ue;) {
       // a block: up to CB consecutive columns that do not straddle a boundary of the line
       const int cj = (g.sym && ux >= g.os) ? ux + skip : ux;
@@ -845,7 +862,7 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
-    const size_t id = ((size_t)w + I) * g.sparts + h;
+    const size_t id = ((size_t)wl + (I - g.I_lo)) * g.sparts + h;
 #pragma unroll
     for (int rr = 0; rr < kRowsPerLane; ++rr) {
       part_d2[id * kRowBlock + rr * kWave + lane] = rs.best[rr];
@@ -858,7 +875,7 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
 __global__ void __launch_bounds__(kWave)
 collide_short_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int ro, int Cn, int S,
                      double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
-                     int32_t *__restrict__ hit) {
+                     int32_t *__restrict__ hit, int raw) {
 #pragma clang fp contract(off)
   const int r = blockIdx.x * kWave + threadIdx.x;
   if (r >= R) return;
@@ -881,6 +898,11 @@ collide_short_kernel(const double *__restrict__ prow, const double *__restrict__
       best = m;
       bestj = j;
     }
+  }
+  if (raw) {      // a part of a pass (msnap_formation_collide_part): squared minimum, no hit flag
+    min_dist[r] = best;
+    partner[r] = (best == INFINITY) ? -1 : bestj;
+    return;
   }
   const double dist = sqrt(best);
   min_dist[r] = dist;
@@ -929,13 +951,19 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
     }
   };
   if (g.total > 0) {
-    // row side: the shares that met this drone's row block
+    // row side: the shares of this launch that met this drone's row block
     const int I = r / kRowBlock;
-    const long long wf = collide_share_of(g, collide_ustart(g, I)), wl = collide_share_of(g, collide_ustart(g, I + 1) - 1);
-    const size_t first = ((size_t)wf + I) * g.sparts * kRowBlock + (r - I * kRowBlock);
-    sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1) * g.sparts);
-    // column side: the row blocks before this drone's own (each left `sparts` entries per column)
-    if (g.sym) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * g.sparts);
+    long long wf = collide_share_of(g, collide_ustart(g, I)), wl = collide_share_of(g, collide_ustart(g, I + 1) - 1);
+    wf = wf < g.w_lo ? g.w_lo : wf;
+    wl = wl >= g.w_hi ? g.w_hi - 1 : wl;
+    if (wl >= wf) {
+      const size_t first = ((size_t)(wf - g.w_lo) + (I - g.I_lo)) * g.sparts * kRowBlock + (r - I * kRowBlock);
+      sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1) * g.sparts);
+    }
+    // column side: the row blocks of this launch before this drone's own (each left `sparts` entries per
+    // column; a part launch leaves the slots it did not reach marked empty)
+    const int Ib = I < g.I_hi + 1 ? I : g.I_hi + 1;
+    if (g.sym && Ib > g.I_lo) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, (Ib - g.I_lo) * g.sparts);
   }
   sD[q][lr] = best;
   sJ[q][lr] = bj;
@@ -950,10 +978,49 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
         bj = j;
       }
     }
-    const double dist = sqrt(best);
-    min_dist[r] = dist;
-    partner[r] = bj;
-    hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+    if (g.part) {     // one part of a pass: squared minima, folded over the parts by collide_finish_kernel
+      min_dist[r] = best;
+      partner[r] = bj;
+    } else {
+      const double dist = sqrt(best);
+      min_dist[r] = dist;
+      partner[r] = bj;
+      hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+    }
+  }
+}
+
+// The parts of a pass folded: minimum over the parts' squared minima (lowest partner wins a tie), distance, hit.
+__global__ void __launch_bounds__(256)
+collide_finish_kernel(const unsigned char *__restrict__ parts, size_t part_stride, int n_parts, int N, int row_offset,
+                      int n_rows, double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
+                      int32_t *__restrict__ hit) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  const int r = row_offset + i;
+  double best = INFINITY;
+  int bj = -1;
+  for (int p = 0; p < n_parts; ++p) {
+    const unsigned char *base = parts + (size_t)p * part_stride;
+    const double v = reinterpret_cast<const double *>(base)[r];
+    const int j = reinterpret_cast<const int32_t *>(base + (size_t)N * sizeof(double))[r];
+    if (j >= 0 && (v < best || (v == best && j < bj))) {
+      best = v;
+      bj = j;
+    }
+  }
+  const double dist = sqrt(best);
+  min_dist[i] = dist;
+  partner[i] = bj;
+  hit[i] = (dist < 2.0 * radius) ? 1 : 0;
+}
+
+// rows [r0, r1) of a part's output marked empty (paths shorter than one sample chunk: the plain kernel fills its rows)
+__global__ void __launch_bounds__(256) collide_part_clear_kernel(double *__restrict__ d2, int32_t *__restrict__ pj, int N) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) {
+    d2[i] = INFINITY;
+    pj[i] = -1;
   }
 }
 
@@ -968,6 +1035,11 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.n_rb = (n_rows + kRowBlock - 1) / kRowBlock;
   g.Rp = g.n_rb * kRowBlock;
   g.sparts = 1;
+  g.w_lo = 0;
+  g.w_hi = 0;
+  g.I_lo = 0;
+  g.I_hi = g.n_rb - 1;
+  g.part = 0;
   if (n_cols == 0) {
     // nobody to collide with: the merge of nothing writes inf / -1 / 0
     g.os = g.oe = 0;
@@ -983,7 +1055,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   }
   if (n_samples < kSampleChunk) {
     hipLaunchKernelGGL(collide_short_kernel, dim3((n_rows + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream,
-                       pos_rows, pos_cols, n_rows, row_offset, n_cols, n_samples, radius, min_dist, partner, hit);
+                       pos_rows, pos_cols, n_rows, row_offset, n_cols, n_samples, radius, min_dist, partner, hit, 0);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
@@ -1031,6 +1103,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.split = (shares - shares % slots) * upw;
   }
   waves = g.split / upw + (g.total - g.split + g.upw_tail - 1) / g.upw_tail;
+  g.w_hi = waves;
   // A small launch (a small swarm, or one of many shards) is as long as ONE share takes -- 16 sample chunks x 8
   // columns are one dependent chain of scalar fetches, 43 us at 512 drones whatever the arithmetic.  While the
   // shares do not fill a quarter of the wave slots (half-full launches lose: 512 of 4096 rows 71 -> 84 us), each
@@ -1055,13 +1128,116 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   int32_t *pj = (int32_t *)(cd + centries);
   int32_t *ci = pj + part_entries;
   hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
-                     n_rows, g.Rp, E, rows_t);
+                     n_rows, g.Rp, E, rows_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
                      (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// One rank's part of the pass over the WHOLE swarm: every unordered pair of the swarm is a (row block, column)
+// unit of one triangular line -- the line a single-GPU launch walks -- and part p of P takes the p-th of P equal
+// contiguous ranges of its 8-column shares.  It evaluates each of its pairs once, credits both drones, and leaves
+// the squared minimum and partner of EVERY drone (+inf / -1 where it met none of the drone's pairs) in
+// out_d2 [N] / out_j [N]; collide_finish_kernel folds the P parts.
+int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const double *pos_all, int part, int n_parts,
+                                  double *out_d2, int32_t *out_j) {
+  if (n_samples < kSampleChunk) {
+    // short paths: the plain kernel on the part's block of rows, one-sidedly against all columns
+    const int r0 = (int)((long long)N * part / n_parts), r1 = (int)((long long)N * (part + 1) / n_parts);
+    hipLaunchKernelGGL(collide_part_clear_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, out_d2, out_j, N);
+    MSNAP_HIP(ctx, hipGetLastError());
+    if (r1 > r0) {
+      hipLaunchKernelGGL(collide_short_kernel, dim3((r1 - r0 + kWave - 1) / kWave), dim3(kWave), 0, ctx->stream,
+                         pos_all + (size_t)r0 * n_samples * 3, pos_all, r1 - r0, r0, N, n_samples, 0.0, out_d2 + r0,
+                         out_j + r0, (int32_t *)nullptr, 1);
+      MSNAP_HIP(ctx, hipGetLastError());
+    }
+    return MSNAP_OK;
+  }
+  CollideGeom g;
+  g.R = N;
+  g.ro = 0;
+  g.Cn = N;
+  g.S = n_samples;
+  g.n_rb = (N + kRowBlock - 1) / kRowBlock;
+  g.os = 0;
+  g.oe = N;
+  g.sym = 1;
+  g.upw = g.upw_tail = kColBlock;
+  g.total = collide_ustart(g, g.n_rb);
+  const long long shares = (g.total + kColBlock - 1) / kColBlock;
+  g.split = shares * kColBlock;
+  g.w_lo = shares * part / n_parts;
+  g.w_hi = shares * (part + 1) / n_parts;
+  g.part = 1;
+  g.sparts = 1;
+  g.I_lo = 0;
+  g.I_hi = -1;
+  const long long waves = g.w_hi - g.w_lo;
+  if (waves > 0) {
+    const long long u0 = collide_share_begin(g, g.w_lo), u1 = collide_share_begin(g, g.w_hi) - 1;
+    while (g.I_lo + 1 < g.n_rb && collide_ustart(g, g.I_lo + 1) <= u0) ++g.I_lo;
+    g.I_hi = g.I_lo;
+    while (g.I_hi + 1 < g.n_rb && collide_ustart(g, g.I_hi + 1) <= u1) ++g.I_hi;
+    // A part that does not fill half of the wave slots is as long as one share's chain of fetches (16 chunks
+    // x 8 columns): its shares are split by sample range.  Measured at 4096 x 91 (rocprofv3, span kernel alone /
+    // merge): an eighth of the line, 1056 shares: 54 / 8 us whole, 43 / 11 us in halves, 40 / 17 us in
+    // quarters, 46 / 31 us in eighths -- every split multiplies the partial entries the merge sweeps; a quarter
+    // of the line, 2112 shares: 72 us whole or in halves.
+    const long long slots = (long long)ctx->n_cu * 4 * 4;
+    if (ctx->collide_sample_parts > 0) {
+      g.sparts = ctx->collide_sample_parts < 8 ? ctx->collide_sample_parts : 8;
+    } else {
+      const int nch = (n_samples + kSampleChunk - 1) / kSampleChunk;
+      while (g.sparts < 8 && waves * g.sparts < slots / 2 && nch / (g.sparts * 2) >= 2) g.sparts *= 2;
+    }
+  }
+  const int nrb = g.I_hi - g.I_lo + 1;                 // row blocks this part touches (0: an empty part)
+  g.Rp = (nrb > 0 ? nrb : 1) * kRowBlock;
+  if (waves * g.sparts > 0x7fffffff) return MSNAP_EINVAL;
+  const size_t part_entries = ((size_t)waves + (size_t)(nrb > 0 ? nrb : 0)) * g.sparts * kRowBlock;
+  const size_t centries = (size_t)(nrb > 0 ? nrb : 0) * g.sparts * (size_t)N;
+  const int E = n_samples * 3;
+  const size_t t_entries = (size_t)g.Rp * E;
+  if ((part_entries + centries) * 12 > ((size_t)16 << 30)) return MSNAP_ENOMEM;
+  int rc = ensure(ctx, ctx->stage[7],
+                  t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
+  if (rc) return rc;
+  double *rows_t = (double *)ctx->stage[7].p;
+  double *pd = rows_t + t_entries;
+  double *cd = pd + part_entries;
+  int32_t *pj = (int32_t *)(cd + centries);
+  int32_t *ci = pj + part_entries;
+  if (waves > 0) {
+    const int r_first = g.I_lo * kRowBlock;
+    const int r_cnt = (N - r_first) < g.Rp ? (N - r_first) : g.Rp;
+    const int ny = (E + 31) / 32;
+    hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, ny + 4), dim3(256), 0, ctx->stream,
+                       pos_all + (size_t)r_first * E, r_cnt, g.Rp, E, rows_t, ny, ci, centries);
+    MSNAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
+                       (const double *)rows_t, pos_all, g, pd, pj, cd, ci);
+    MSNAP_HIP(ctx, hipGetLastError());
+  } else {
+    g.total = 0;   // the merge of nothing: +inf / -1 everywhere
+  }
+  hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
+                     ctx->stream, pd, pj, g, cd, ci, 0.0, out_d2, out_j, (int32_t *)nullptr);
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+int launch_formation_collide_finish(msnap_ctx *ctx, int N, int n_parts, const void *parts, size_t part_stride,
+                                    int row_offset, int n_rows, double radius, double *min_dist, int32_t *partner,
+                                    int32_t *hit) {
+  hipLaunchKernelGGL(collide_finish_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream,
+                     (const unsigned char *)parts, part_stride, n_parts, N, row_offset, n_rows, radius, min_dist, partner,
+                     hit);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

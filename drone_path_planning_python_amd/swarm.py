@@ -1,13 +1,16 @@
 """Sharding a swarm over the GPUs of one node (one process per GPU).
 
 The solve needs no communication: drones are split into contiguous blocks, one
-per rank.  The formation (drone-vs-drone) pass has one real exchange step: every
-rank samples its own shard, the sampled positions are all-gathered (RCCL over
-xGMI when the process group is "nccl"; "gloo" on CPU for the tests) and each
-rank then checks its own rows against all columns -- row-owned results, no
-reduction.  The mesh sweep replicates the (tiny) mesh and shards the drones; it
-depends on the rank's own samples only, so with a second context (`side_ctx`) it
-runs on a side stream next to the exchange and the pairwise pass.
+per rank.  The formation (drone-vs-drone) pass exchanges twice: every rank samples
+its own shard and the sampled positions are all-gathered (RCCL over xGMI when the
+process group is "nccl"; "gloo" on CPU for the tests); then the swarm's unordered
+pairs -- one triangular line of (row block, column) units -- are split into `world`
+equal contiguous parts, rank r evaluates part r (every pair on exactly ONE rank,
+both drones credited), the per-drone partial minima (12 bytes per drone and rank)
+are all-gathered and every rank folds them for the rows it owns.  The mesh sweep
+replicates the (tiny) mesh and shards the drones; it depends on the rank's own
+samples only, so with a second context (`side_ctx`) it runs on a side stream next
+to the exchanges and the pairwise pass.
 
 torch / torch.distributed are plumbing here (device memory + the collective);
 all arithmetic happens in libmsnap through the `compute` object, by default a
@@ -105,6 +108,26 @@ class DeviceCompute:
                                               pos_all, radius, md, partner, hit)
         return md, partner, hit
 
+    def collide_part(self, pos_all, part, n_parts):
+        """This rank's part of the pass over the whole swarm: uint8 [formation_part_bytes(N)] (squared minima
+        of every drone over the pairs of this part, then the partners)."""
+        n = pos_all.shape[0]
+        out = self.torch.empty((self.ctx.formation_part_bytes(n),), dtype=self.torch.uint8, device=self.device)
+        if n:
+            self.ctx.formation_collide_part_device(n, pos_all.shape[1], pos_all, part, n_parts, out)
+        return out
+
+    def collide_finish(self, parts, n_total, row_offset, n_rows, radius):
+        """Fold the gathered parts (uint8 [P, formation_part_bytes(N)]) for the rows this rank owns."""
+        torch = self.torch
+        md = torch.empty((n_rows,), dtype=torch.float64, device=self.device)
+        partner = torch.empty((n_rows,), dtype=torch.int32, device=self.device)
+        hit = torch.empty((n_rows,), dtype=torch.int32, device=self.device)
+        if n_rows:
+            self.ctx.formation_collide_finish_device(n_total, parts.shape[0], parts, row_offset, n_rows, radius,
+                                                     md, partner, hit)
+        return md, partner, hit
+
     def _mesh_on(self, ctx, pos, tris, radius, md=None, hit=None):
         torch = self.torch
         n = pos.shape[0]
@@ -145,6 +168,18 @@ class DeviceCompute:
             self.main.wait_stream(self.side)
         return out
 
+    def mesh_abort(self):
+        """Join a pending sweep and forget it: what a caller's `finally` runs when something between
+        `mesh_begin` and `mesh_end` raised, so that the main stream is ordered behind the side stream before
+        the sweep's buffers can be recycled and the next `mesh_begin` is not refused."""
+        if self._mesh_pending is not None:
+            self.mesh_end()
+
+    def close(self):
+        """Drop the wrapper of the side context's stream (call before closing `side_ctx`)."""
+        self.mesh_abort()
+        self.side = None
+
 
 @dataclass
 class FormationResult:
@@ -182,12 +217,23 @@ def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, t
     return torch.cat(parts, dim=0)
 
 
+def all_gather_parts(part_local, world: int, dist, torch):
+    """All-gather the ranks' part blocks (uint8 [B] each) into [world, B]: the second, small collective of the
+    formation pass (12 bytes per drone and rank)."""
+    if world == 1:
+        return part_local.reshape(1, -1)
+    gathered = torch.empty((world * part_local.shape[0],), dtype=part_local.dtype, device=part_local.device)
+    dist.all_gather_into_tensor(gathered, part_local.contiguous())
+    return gathered.reshape(world, -1)
+
+
 def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, rank: int, dt: float,
                    n_samples: int, radius: float, dist=None, torch=None, status_local=None,
                    mesh_tris=None) -> FormationResult:
-    """Sample the local shard, exchange, collide own rows against everybody; with `mesh_tris`
-    ([T, 3, 3]) also sweep the local shard against the mesh, started right behind the sampler so
-    that a compute object with a side stream overlaps it with the exchange and the pairwise pass.
+    """Sample the local shard, exchange, evaluate this rank's part of the swarm's pairs, exchange the
+    partial minima and fold them for the own rows (one rank: one symmetric launch, no exchange); with
+    `mesh_tris` ([T, 3, 3]) also sweep the local shard against the mesh, started right behind the sampler
+    so that a compute object with a side stream overlaps it with the exchanges and the pairwise pass.
 
     `status_local` (the solve's per-drone status of this shard): a failed solve leaves NaN
     coefficients, and NaN samples never win a minimum (include/msnap.h) -- such a drone would
@@ -200,13 +246,23 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
     overlapped = mesh_tris is not None and hasattr(compute, "mesh_begin")
     if overlapped:
         compute.mesh_begin(pos_local, mesh_tris, radius)
-    pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch) if world > 1 else pos_local
-    md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)
-    mmd = mhit = None
-    if overlapped:
-        mmd, mhit = compute.mesh_end()
-    elif mesh_tris is not None:
-        mmd, mhit = compute.mesh(pos_local, mesh_tris, radius)
+    try:
+        if world > 1:
+            pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch)
+            part = compute.collide_part(pos_all, rank, world)
+            parts = all_gather_parts(part, world, dist, torch)
+            md, partner, hit = compute.collide_finish(parts, n_total, lo, hi - lo, radius)
+        else:
+            pos_all = pos_local
+            md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)
+        mmd = mhit = None
+        if overlapped:
+            mmd, mhit = compute.mesh_end()
+        elif mesh_tris is not None:
+            mmd, mhit = compute.mesh(pos_local, mesh_tris, radius)
+    finally:
+        if overlapped and hasattr(compute, "mesh_abort"):
+            compute.mesh_abort()      # (a no-op unless something above raised between begin and end)
     return FormationResult(lo, hi, md, partner, hit, pos_all, mmd, mhit)
 
 

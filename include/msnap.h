@@ -227,6 +227,31 @@ int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, i
                                    const double *pos_cols, double radius,
                                    double *min_dist, int32_t *partner, int32_t *hit);
 
+/* ---- the same pass split over the ranks of a job: every unordered pair on exactly ONE rank --------
+ * BASELINE.json north_star: "the drone batch shards across the 8 GPUs ... with an RCCL all-gather for the
+ * inter-drone formation collision pass".  After the all-gather every rank holds pos_all [n_drones][n_samples][3].
+ * The swarm's unordered pairs form one triangular line of (128-row block, column) units -- the line a single
+ * msnap_formation_collide launch walks; part `part` of `n_parts` evaluates the part-th of n_parts equal contiguous
+ * ranges of it, each pair once, and credits both drones.  part_out (msnap_formation_part_bytes(n_drones) bytes,
+ * 8-byte aligned) receives, for EVERY drone of the swarm, the squared minimum over the pairs this part met
+ * (double [n_drones]) followed by the partner (int32 [n_drones]; +inf / -1 where it met none).  The ranks exchange
+ * their part_out blocks (one more all-gather of n_parts x 12 B x n_drones) and msnap_formation_collide_finish folds
+ * them for the rows [row_offset, row_offset + n_rows) a rank owns: minimum over the parts (lowest partner wins a
+ * tie), distance, hit -- bit for bit what one msnap_formation_collide over the whole swarm returns.
+ *   parts [n_parts] blocks of msnap_formation_part_bytes(n_drones) bytes, part p at offset p * that
+ */
+size_t msnap_formation_part_bytes(int n_drones);
+int msnap_formation_collide_part(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all,
+                                 int part, int n_parts, void *part_out);
+int msnap_formation_collide_part_device(msnap_ctx *ctx, int n_drones, int n_samples,
+                                        const double *pos_all, int part, int n_parts, void *part_out);
+int msnap_formation_collide_finish(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts,
+                                   int row_offset, int n_rows, double radius, double *min_dist,
+                                   int32_t *partner, int32_t *hit);
+int msnap_formation_collide_finish_device(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts,
+                                          int row_offset, int n_rows, double radius, double *min_dist,
+                                          int32_t *partner, int32_t *hit);
+
 /* ---- drone-vs-mesh sweep against resources/stl obstacles (new capability) ----------
  *   tris [n_tris][3][3] fp64 vertices (binary STL float32 widened by the caller)
  *   min_dist [n_drones] min over samples and triangles of the point-triangle distance

@@ -1,8 +1,8 @@
 """The N > 1 path on CPU: world_size-2 (and 3) gloo process groups exercise the
-drone sharding and the all-gather exchange of swarm.formation_pass.  The device
-arithmetic is replaced by the oracle (the checker) behind the same three-method
-interface DeviceCompute offers, so what is tested is the distributed logic:
-partition, padding, gather order, row offsets."""
+drone sharding and the two all-gather exchanges of swarm.formation_pass (positions,
+then the per-part partial minima).  The device arithmetic is replaced by the oracle
+(the checker) behind the interface DeviceCompute offers, so what is tested is the
+distributed logic: partition, padding, gather order, row offsets, the fold of the parts."""
 import os
 import socket
 import sys
@@ -49,6 +49,39 @@ class OracleCompute:
             d2[row_offset + i] = np.inf
             j = int(np.argmin(d2))
             md[i], partner[i] = np.sqrt(d2[j]), j
+        return torch.from_numpy(md), torch.from_numpy(partner), torch.from_numpy((md < 2 * radius).astype(np.int32))
+
+
+    # the pass in parts (every unordered pair on exactly one rank): the stand-in deals the pairs (i, j), i < j,
+    # to part (i + j) % n_parts -- any partition exercises the exchange and the fold
+    def collide_part(self, pos_all, part, n_parts):
+        allp = pos_all.numpy()
+        N = allp.shape[0]
+        d2 = np.full(N, np.inf)
+        pj = np.full(N, -1, dtype=np.int32)
+        for i in range(N):
+            d = allp - allp[i][None]
+            row = np.fmin.reduce(self.O.fma_square(d[..., 2], self.O.fma_square(d[..., 1], d[..., 0] * d[..., 0])), axis=1)
+            for j in range(N):
+                if j != i and (i + j) % n_parts == part and (row[j] < d2[i] or (row[j] == d2[i] and j < pj[i])):
+                    d2[i], pj[i] = row[j], j
+        out = np.zeros(((N * 12 + 7) // 8 * 8,), dtype=np.uint8)
+        out[:8 * N] = d2.view(np.uint8)
+        out[8 * N:12 * N] = pj.view(np.uint8)
+        return torch.from_numpy(out)
+
+    def collide_finish(self, parts, n_total, row_offset, n_rows, radius):
+        P = parts.shape[0]
+        pb = parts.numpy()
+        md = np.full(n_rows, np.inf)
+        partner = np.full(n_rows, -1, dtype=np.int32)
+        for p in range(P):
+            d2 = pb[p, :8 * n_total].copy().view(np.float64)[row_offset:row_offset + n_rows]
+            pj = pb[p, 8 * n_total:12 * n_total].copy().view(np.int32)[row_offset:row_offset + n_rows]
+            take = (pj >= 0) & ((d2 < md) | ((d2 == md) & (pj < partner)))
+            md = np.where(take, d2, md)
+            partner = np.where(take, pj, partner)
+        md = np.sqrt(md)
         return torch.from_numpy(md), torch.from_numpy(partner), torch.from_numpy((md < 2 * radius).astype(np.int32))
 
 

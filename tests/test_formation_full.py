@@ -119,6 +119,21 @@ def test_full_size_formation_pipeline_matches_fixture(cfg, fgold, ctx7):
         np.testing.assert_array_equal(smd, md[lo:hi])
         np.testing.assert_array_equal(sp, partner[lo:hi])
         np.testing.assert_array_equal(sh, hit[lo:hi])
+    # as on G GPUs: every rank of G = 2, 4, 8 emulated here -- rank p evaluates part p of the swarm's pairs
+    # (each unordered pair on exactly one rank), the [G] part blocks are what the second all-gather moves,
+    # and the fold must be the single-GPU result bit for bit
+    for Gp in (2, 4, 8):
+        parts = np.stack([ctx7.formation_collide_part(pos, p, Gp) for p in range(Gp)])
+        for r in {0, Gp - 1, Gp // 2}:
+            lo, hi = r * N // Gp, (r + 1) * N // Gp
+            fmd, fp, fh = ctx7.formation_collide_finish(parts, N, synthetic.DRONE_RADIUS, row_offset=lo, n_rows=hi - lo)
+            np.testing.assert_array_equal(fmd, md[lo:hi])
+            np.testing.assert_array_equal(fp, partner[lo:hi])
+            np.testing.assert_array_equal(fh, hit[lo:hi])
+        # the parts are disjoint in pairs: a drone's minimum is attained in at least one of them and no part
+        # reports a partner the drone never met
+        d2s = np.stack([ctx7.split_part(parts[p], N)[0] for p in range(Gp)])
+        assert np.array_equal(np.sqrt(d2s.min(axis=0)), md)
     if cfg == 3:
         mmd, mhit = ctx7.mesh_sweep(pos, _scene(), synthetic.DRONE_RADIUS)
         np.testing.assert_array_equal(np.nonzero(mhit)[0], fgold["cfg3_mesh_hit_idx"])
@@ -153,3 +168,36 @@ def test_collision_passes_with_failed_and_missing_drones(ctx7):
             raise AssertionError("sampled a shard with failed drones")
     with pytest.raises(ValueError):
         sw.formation_pass(Comp(), coef, dur, 70, 1, 0, 0.1, 40, 0.2, status_local=status)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,S,parts", [(70, 40, 3), (129, 13, 2), (300, 31, 5), (515, 7, 8), (1000, 24, 7),
+                                       (40, 4, 3), (1, 12, 2), (2, 12, 4), (257, 91, 16)])
+def test_collide_in_parts_equals_the_oracle(ctx7, n, S, parts):
+    """msnap_formation_collide_part / _finish on odd shapes: parts that start and end inside a row block, more
+    parts than shares, a single drone, paths shorter than one sample chunk, a NaN drone, exact ties on a
+    lattice.  Folded over the parts: bit for bit the oracle's pass over the whole swarm."""
+    rng = np.random.default_rng(1000 * n + S)
+    pos = rng.uniform(-2.0, 2.0, size=(n, S, 3))
+    pos[: n // 2] = np.round(pos[: n // 2] * 2.0) / 2.0           # lattice positions: exact ties between partners
+    if n > 20:
+        pos[11] = np.nan                                           # a failed drone
+    ref = c_oracle.formation_collide(pos, 0.3)
+    blocks = np.stack([ctx7.formation_collide_part(pos, p, parts) for p in range(parts)])
+    md, partner, hit = ctx7.formation_collide_finish(blocks, n, 0.3)
+    np.testing.assert_array_equal(md, ref[0])
+    np.testing.assert_array_equal(partner, ref[1])
+    np.testing.assert_array_equal(hit, ref[2])
+    lo, hi = n // 3, max(n // 3, 2 * n // 3)
+    md2, p2, h2 = ctx7.formation_collide_finish(blocks, n, 0.3, row_offset=lo, n_rows=hi - lo)
+    np.testing.assert_array_equal(md2, ref[0][lo:hi])
+    np.testing.assert_array_equal(p2, ref[1][lo:hi])
+    # forced sample parts (what a small part launch chooses by itself)
+    ctx7.set_option("collide_sample_parts", 4)
+    try:
+        blocks4 = np.stack([ctx7.formation_collide_part(pos, p, parts) for p in range(parts)])
+    finally:
+        ctx7.set_option("collide_sample_parts", 0)
+    md4, p4, _ = ctx7.formation_collide_finish(blocks4, n, 0.3)
+    np.testing.assert_array_equal(md4, ref[0])
+    np.testing.assert_array_equal(p4, ref[1])
