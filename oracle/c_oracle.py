@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libmsnap_oracle.so")
+# MSNAP_ORACLE_LIB: the sanitizer build of the same file (oracle/Makefile `sanitize`, tests/test_sanitizers.py)
+_PATH = os.environ.get("MSNAP_ORACLE_LIB") or os.path.join(_HERE, "libmsnap_oracle.so")
 _lib = None
 
 

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Extended-precision pin of ORDER 9 (BASELINE.json configs[4]).
+
+The reference hard-codes 8 coefficients (src/optimizations/calculatingTrajectories.py:48-49,63),
+so order 9 has no reference implementation.  This script solves the natural order-(2k-1)
+generalisation, k = 5, with mpmath at 60 significant digits in TWO formulations and asserts that
+they agree before anything is stored:
+
+  collocation   the reference's square system with 10 coefficients per segment: k endpoint rows at
+                each end (d^0..d^4 = [w, 0, 0, 0, 0]), two position rows and continuity of d^1..d^8
+                at every interior knot (calculatingTrajectories.py:65-131 with 8 -> 10; the row
+                layout is the one oracle/msnap_oracle.py::assemble_1d restates, incl. the start rows
+                evaluated at the absolute first time)
+  KKT / QP      minimise sum_seg int_0^T (p^(5))^2 dt  s.t.  waypoint interpolation, d^1..d^4 = 0 at
+                both ends, C^4 continuity -- the north-star's formulation; its stationarity
+                conditions are the d^5..d^8 continuity rows of the collocation system (only for
+                paths that start at t = 0: the reference's start-row quirk has no QP counterpart)
+
+Inputs are the float64 waypoints / times of seeded synthetic swarms taken exactly (mpf of a double is
+exact); outputs are the 60-digit solutions rounded once to float64.
+
+Runs in the build container (mpmath is importable there; nothing of the reference is needed):
+    python3 tests/golden/make_order9_golden.py        -> tests/golden/order9_golden.npz
+"""
+import os
+import sys
+import time
+
+import mpmath as mp
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from drone_path_planning_python_amd import synthetic  # noqa: E402  (seeded inputs only: NumPy, no GPU)
+
+mp.mp.dps = 60
+NC = 10            # coefficients per segment
+K = NC // 2        # 5: endpoint derivative rows per end
+
+
+def falling(k, j):
+    """k! / (k-j)!"""
+    f = mp.mpf(1)
+    for q in range(k - j + 1, k + 1):
+        f *= q
+    return f
+
+
+def deriv_row(j, t):
+    """j-th derivative of sum_k c_k t^k at t as a row over c (0**0 == 1)."""
+    row = [mp.mpf(0)] * NC
+    for k in range(j, NC):
+        row[k] = falling(k, j) * (t ** (k - j) if k > j else mp.mpf(1))
+    return row
+
+
+def lu_factor(A):
+    """In-place LU with partial pivoting on a list-of-lists of mpf; returns the pivot order."""
+    n = len(A)
+    piv = list(range(n))
+    for c in range(n):
+        p = max(range(c, n), key=lambda r: abs(A[r][c]))
+        if A[p][c] == 0:
+            raise ZeroDivisionError("singular system")
+        if p != c:
+            A[c], A[p] = A[p], A[c]
+            piv[c], piv[p] = piv[p], piv[c]
+        inv = 1 / A[c][c]
+        rowc = A[c]
+        for r in range(c + 1, n):
+            rowr = A[r]
+            if rowr[c] == 0:
+                continue
+            f = rowr[c] * inv
+            rowr[c] = f
+            for q in range(c + 1, n):
+                if rowc[q] != 0:
+                    rowr[q] -= f * rowc[q]
+    return piv
+
+
+def lu_solve(A, piv, b):
+    n = len(A)
+    x = [b[piv[i]] for i in range(n)]
+    for r in range(n):
+        s = x[r]
+        rowr = A[r]
+        for q in range(r):
+            if rowr[q] != 0:
+                s -= rowr[q] * x[q]
+        x[r] = s
+    for r in range(n - 1, -1, -1):
+        s = x[r]
+        rowr = A[r]
+        for q in range(r + 1, n):
+            if rowr[q] != 0:
+                s -= rowr[q] * x[q]
+        x[r] = s / rowr[r]
+    return x
+
+
+def collocation(times, wp):
+    """times [m] float64, wp [m, 4] float64 -> coef[M][4][NC] (mpf), the generalised reference system."""
+    m = len(times)
+    M = m - 1
+    n = NC * M
+    t = [mp.mpf(float(x)) for x in times]
+    A = [[mp.mpf(0)] * n for _ in range(n)]
+    B = [[mp.mpf(0)] * n for _ in range(4)]
+    prev = mp.mpf(0)
+    for i in range(m):
+        ti = t[i] - prev
+        if i == 0 or i == M:
+            for j in range(K):
+                row = deriv_row(j, ti)
+                base = 0 if i == 0 else NC * (M - 1)
+                r = j if i == 0 else n - K + j
+                A[r][base:base + NC] = row
+            for a in range(4):
+                B[a][0 if i == 0 else n - K] = mp.mpf(float(wp[i, a]))
+        else:
+            base = K + (i - 1) * NC
+            for j in range(1, NC - 1):
+                A[base + j - 1][NC * (i - 1):NC * i] = deriv_row(j, ti)
+                A[base + j - 1][NC * i:NC * (i + 1)] = [-v for v in deriv_row(j, mp.mpf(0))]
+            A[base + NC - 2][NC * (i - 1):NC * i] = deriv_row(0, ti)
+            A[base + NC - 1][NC * i:NC * (i + 1)] = deriv_row(0, mp.mpf(0))
+            for a in range(4):
+                B[a][base + NC - 2] = mp.mpf(float(wp[i, a]))
+                B[a][base + NC - 1] = mp.mpf(float(wp[i, a]))
+        prev = t[i]
+    piv = lu_factor(A)
+    sol = [lu_solve(A, piv, B[a]) for a in range(4)]
+    return [[[sol[a][NC * s + q] for q in range(NC)] for a in range(4)] for s in range(M)]
+
+
+def kkt(times, wp):
+    """The minimum-crackle QP through its KKT system (paths with times[0] == 0)."""
+    assert float(times[0]) == 0.0
+    m = len(times)
+    M = m - 1
+    t = [mp.mpf(float(x)) for x in times]
+    T = [t[i + 1] - t[i] for i in range(M)]
+    nv = NC * M
+    rows, rhs = [], [[] for _ in range(4)]
+
+    def add(seg_rows, vals):
+        row = [mp.mpf(0)] * nv
+        for seg, r in seg_rows:
+            for q in range(NC):
+                row[NC * seg + q] += r[q]
+        rows.append(row)
+        for a in range(4):
+            rhs[a].append(vals[a])
+
+    zero4 = [mp.mpf(0)] * 4
+    w = [[mp.mpf(float(wp[i, a])) for a in range(4)] for i in range(m)]
+    add([(0, deriv_row(0, mp.mpf(0)))], w[0])
+    for j in range(1, K):
+        add([(0, deriv_row(j, mp.mpf(0)))], zero4)
+    for i in range(1, M):
+        add([(i - 1, deriv_row(0, T[i - 1]))], w[i])
+        add([(i, deriv_row(0, mp.mpf(0)))], w[i])
+        for j in range(1, K):     # C^1..C^4
+            add([(i - 1, deriv_row(j, T[i - 1])), (i, [-v for v in deriv_row(j, mp.mpf(0))])], zero4)
+    add([(M - 1, deriv_row(0, T[M - 1]))], w[M])
+    for j in range(1, K):
+        add([(M - 1, deriv_row(j, T[M - 1]))], zero4)
+    nc = len(rows)
+    n = nv + nc
+    A = [[mp.mpf(0)] * n for _ in range(n)]
+    for s in range(M):
+        for a in range(K, NC):
+            for b in range(K, NC):
+                p = a + b - 2 * K + 1
+                A[NC * s + a][NC * s + b] = 2 * falling(a, K) * falling(b, K) * T[s] ** p / p
+    for r in range(nc):
+        for c in range(nv):
+            if rows[r][c] != 0:
+                A[nv + r][c] = rows[r][c]
+                A[c][nv + r] = rows[r][c]
+    piv = lu_factor(A)
+    sol = [lu_solve(A, piv, [mp.mpf(0)] * nv + rhs[a]) for a in range(4)]
+    return [[[sol[a][NC * s + q] for q in range(NC)] for a in range(4)] for s in range(M)]
+
+
+def rel_diff(x, y):
+    """max over (segment-block) of |x - y| / max|y| per axis -- the parity metric of the tests."""
+    worst = mp.mpf(0)
+    M = len(x)
+    for a in range(4):
+        den = max(abs(y[s][a][q]) for s in range(M) for q in range(NC))
+        num = max(abs(x[s][a][q] - y[s][a][q]) for s in range(M) for q in range(NC))
+        worst = max(worst, num / den)
+    return worst
+
+
+def to_f64(c):
+    return np.array([[[float(v) for v in ax] for ax in seg] for seg in c], dtype=np.float64)
+
+
+def main():
+    out = {}
+    # (name, seed, drones, segments, shared grid, drones cross-checked against the KKT form, t0 quirk)
+    cases = [("m10", 9100, 32, 10, False, 4, False), ("m10s", 9101, 8, 10, True, 1, False),
+             ("m10q", 9102, 4, 10, False, 0, True), ("m2", 9202, 4, 2, False, 1, False),
+             ("m3", 9203, 4, 3, False, 1, False), ("m4", 9104, 4, 4, False, 1, False),
+             ("m5", 9105, 4, 5, False, 1, False), ("m6", 9106, 4, 6, False, 1, False),
+             ("m7", 9107, 4, 7, False, 1, False), ("m8", 9108, 4, 8, False, 1, False),
+             ("m9", 9109, 4, 9, False, 1, False), ("m12", 9112, 4, 12, False, 1, False),
+             ("m16", 9116, 4, 16, False, 1, False), ("m20", 9120, 4, 20, False, 1, False),
+             ("m20s", 9121, 2, 20, True, 1, False)]
+    worst_kkt = mp.mpf(0)
+    for name, seed, n, M, shared, nk, quirk in cases:
+        wp, t = synthetic.swarm(seed, n, M, shared_times=shared)
+        if quirk:
+            t = t + 0.2 * np.arange(1, n + 1)[:, None]        # first time != 0 (start rows at t[0], Appendix A)
+        coef = np.empty((n, M, 4, NC))
+        for d in range(n):
+            tt = t if t.ndim == 1 else t[d]
+            t0 = time.time()
+            c = collocation(tt, wp[d])
+            coef[d] = to_f64(c)
+            msg = f"{name}[{d}] M={M}: collocation {time.time() - t0:.1f} s"
+            if d < nk:
+                t0 = time.time()
+                q = kkt(tt, wp[d])
+                diff = rel_diff(q, c)
+                worst_kkt = max(worst_kkt, diff)
+                msg += f", KKT {time.time() - t0:.1f} s, |KKT - collocation| = {mp.nstr(diff, 3)}"
+                assert diff < mp.mpf(10) ** -40, (name, d, diff)
+            print(msg, flush=True)
+        out[name + "_wp"], out[name + "_t"], out[name + "_coef"] = wp, t, coef
+    out["kkt_vs_collocation_max"] = np.float64(float(worst_kkt))
+    out["digits"] = np.int64(mp.mp.dps)
+    np.savez_compressed(os.path.join(HERE, "order9_golden.npz"), **out)
+    print("wrote order9_golden.npz; worst KKT-vs-collocation difference", mp.nstr(worst_kkt, 3))
+
+
+if __name__ == "__main__":
+    main()

@@ -132,3 +132,26 @@ def test_order9_reduces_and_is_consistent():
                 left, right = O.poly_derivative(left), O.poly_derivative(right)
                 lv, rv = O.poly_eval(left, dur[i]), O.poly_eval(right, 0.0)
                 assert abs(lv - rv) <= 1e-6 * max(1.0, abs(lv))
+
+
+def test_order9_fixture_pins_the_oracles():
+    """tests/golden/order9_golden.npz (make_order9_golden.py): 60-digit mpmath solutions of the order-9
+    collocation system, cross-checked there against the order-9 KKT / QP formulation (SURVEY.md 8c (iii):
+    order 9 has no reference implementation).  Both oracles must sit within 1e-9 of it."""
+    import c_oracle
+    g = np.load(os.path.join(GOLDEN_DIR, "order9_golden.npz"))
+    assert float(g["kkt_vs_collocation_max"]) < 1e-40 and int(g["digits"]) >= 50
+    names = sorted({k[:-3] for k in g.files if k.endswith("_wp")})
+    assert {"m10", "m10s", "m10q", "m16", "m20"} <= set(names)
+    worst = 0.0
+    for name in names:
+        wp, t, ref = g[name + "_wp"], g[name + "_t"], g[name + "_coef"]
+        assert ref.shape == (wp.shape[0], wp.shape[1] - 1, 4, 10)
+        for coef in (O.solve_batch_fast(wp, t, ncoef=10)[0],
+                     c_oracle.solve_batch(wp, t, ncoef=10, faithful=True, n_threads=0)[0]):
+            num = np.abs(coef - ref).max(axis=(1, 3))
+            worst = max(worst, float((num / np.abs(ref).max(axis=(1, 3))).max()))
+    assert worst <= 1e-9, worst
+    # ... and the generalisation is the reference's system at 8 coefficients (k = 4): same assembly code
+    A8, _ = O.assemble_1d(g["m4_t"][0], g["m4_wp"][0, :, 0], 8)
+    assert A8.shape == (32, 32)
