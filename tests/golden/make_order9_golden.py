@@ -215,7 +215,7 @@ def main():
     for name, seed, n, M, shared, nk, quirk in cases:
         wp, t = synthetic.swarm(seed, n, M, shared_times=shared)
         if quirk:
-            t = t + 0.2 * np.arange(1, n + 1)[:, None]        # first time != 0 (start rows at t[0], Appendix A)
+            t = t + 0.1 * np.arange(1, n + 1)[:, None]        # first time != 0 (start rows at t[0], Appendix A); < min T_0
         coef = np.empty((n, M, 4, NC))
         for d in range(n):
             tt = t if t.ndim == 1 else t[d]

