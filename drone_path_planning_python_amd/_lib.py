@@ -57,6 +57,9 @@ SIGNATURES = {
     "msnap_snap_cost_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_formation_collide": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_collide_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _D, _VP, _VP, _VP]),
+    "msnap_collide_rows_t_doubles": (ctypes.c_size_t, [_I, _I]),
+    "msnap_sample_collide_device": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _VP, _VP]),
+    "msnap_formation_collide_t_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_part_bytes": (ctypes.c_size_t, [_I]),
     "msnap_formation_collide_part": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
     "msnap_formation_collide_part_device": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),

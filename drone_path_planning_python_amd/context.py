@@ -226,10 +226,18 @@ class Context:
             return self.solve_grid(wp, out=out)
 
     def prepare_grid_device(self, n_seg, t):
-        with self._lock:
-            self._ck(self._lib.msnap_grid_prepare_device(self._h, int(n_seg), _ptr(t)))
-        self._grid_m = int(n_seg) + 1
-        self._grid_host = None
+        with self._glock:     # (under the grid lock like prepare_grid: solve_on_grid must not see a half-updated grid)
+            with self._lock:
+                self._ck(self._lib.msnap_grid_prepare_device(self._h, int(n_seg), _ptr(t)))
+            self._grid_m = int(n_seg) + 1
+            self._grid_host = None
+
+    def grid_waypoints(self) -> int:
+        """Waypoints per drone of the grid this context was last prepared for (raises MSNAP_ENOGRID without one)."""
+        m = getattr(self, "_grid_m", None)
+        if m is None:
+            _lib.check(self._lib, self._h, -7)
+        return int(m)
 
     def solve_grid(self, wp, out=None):
         """wp [N, m, 4] on the prepared grid -> coef, dur, status (as solve_batch)."""
@@ -248,7 +256,13 @@ class Context:
                                                    status.ctypes.data_as(ctypes.c_void_p)))
             return coef, dur, status
 
-    def solve_grid_device(self, n_drones, wp, coef, dur, status):
+    def solve_grid_device(self, n_drones, wp, coef, dur, status, n_seg=None):
+        """Device pointers.  msnap_solve_grid_device takes no segment count -- it writes n_drones x (segments of
+        the prepared grid) blocks -- so pass `n_seg`, the segment count the buffers were sized for: a mismatch
+        with the prepared grid raises here instead of writing past them."""
+        if n_seg is not None and int(n_seg) + 1 != self.grid_waypoints():
+            raise ValueError(f"solve_grid_device: buffers sized for {int(n_seg)} segments, the prepared grid has "
+                             f"{self.grid_waypoints() - 1}")
         with self._lock:
             self._ck(self._lib.msnap_solve_grid_device(self._h, int(n_drones), _ptr(wp), _ptr(coef), _ptr(dur),
                                                       _ptr(status)))
@@ -353,6 +367,22 @@ class Context:
         with self._lock:
             self._ck(self._lib.msnap_formation_collide_device(
                 self._h, int(n_rows), int(row_offset), int(n_cols), int(n_samples), _ptr(pos_rows),
+                _ptr(pos_cols), float(radius), _ptr(min_dist), _ptr(partner), _ptr(hit)))
+
+    def collide_rows_t_doubles(self, n_rows: int, n_samples: int) -> int:
+        return int(self._lib.msnap_collide_rows_t_doubles(int(n_rows), int(n_samples)))
+
+    def sample_collide_device(self, n_drones, n_seg, coef, dur, dt, n_samples, pos, pos_t):
+        """The sampler with its second output: the transposed row image the pairwise pass reads."""
+        with self._lock:
+            self._ck(self._lib.msnap_sample_collide_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
+                                                          float(dt), int(n_samples), _ptr(pos), _ptr(pos_t)))
+
+    def formation_collide_t_device(self, n_rows, row_offset, n_cols, n_samples, pos_rows_t, pos_rows, pos_cols, radius,
+                                   min_dist, partner, hit):
+        with self._lock:
+            self._ck(self._lib.msnap_formation_collide_t_device(
+                self._h, int(n_rows), int(row_offset), int(n_cols), int(n_samples), _ptr(pos_rows_t), _ptr(pos_rows),
                 _ptr(pos_cols), float(radius), _ptr(min_dist), _ptr(partner), _ptr(hit)))
 
     # ---- the pairwise pass in parts: every unordered pair on exactly one rank (include/msnap.h) ----

@@ -67,6 +67,8 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "no_twin9")) return &ctx->no_twin9;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;
+  if (!strcmp(name, "collide_no_sym")) return &ctx->collide_no_sym;
+  if (!strcmp(name, "collide_last_sym")) return &ctx->collide_last_sym;   // (read: what the last pass did)
   if (!strcmp(name, "own_stream_priority")) return &ctx->own_stream_priority;   // (read side; set has its own branch)
   return nullptr;
 }
@@ -557,7 +559,23 @@ int msnap_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *c
   if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
   if (!coef || !dur || !pos) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, n_axes, pos);
+  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, n_axes, pos, nullptr);
+}
+
+size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples) {
+  if (n_rows <= 0 || n_samples <= 0) return 0;
+  return ((size_t)n_rows + 127) / 128 * 128 * (size_t)n_samples * 3;
+}
+
+int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
+                                double dt, int n_samples, double *pos, double *pos_t) {
+  if (!sample_args_ok(ctx, n_drones, n_samples, 3, dt)) return MSNAP_EINVAL;
+  int rc = check_seg(ctx, n_seg);
+  if (rc) return rc;
+  if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
+  if (!coef || !dur || !pos || !pos_t) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, 3, pos, pos_t);
 }
 
 int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
@@ -577,7 +595,7 @@ int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, co
   MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[2].p, coef, b_coef, hipMemcpyHostToDevice, ctx->stream));
   MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[3].p, dur, b_dur, hipMemcpyHostToDevice, ctx->stream));
   rc = launch_sample(ctx, n_drones, n_seg, (const double *)ctx->stage[2].p, (const double *)ctx->stage[3].p,
-                     dt, n_samples, n_axes, (double *)ctx->stage[6].p);
+                     dt, n_samples, n_axes, (double *)ctx->stage[6].p, nullptr);
   if (rc) return rc;
   MSNAP_HIP(ctx, hipMemcpyAsync(pos, ctx->stage[6].p, b_pos, hipMemcpyDeviceToHost, ctx->stream));
   MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -666,7 +684,19 @@ int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, i
   if (!pos_rows || (n_cols > 0 && !pos_cols) || !min_dist || !partner || !hit) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
   return launch_formation_collide(ctx, n_rows, row_offset, n_cols, n_samples, pos_rows, pos_cols, radius,
-                                  min_dist, partner, hit);
+                                  min_dist, partner, hit, nullptr);
+}
+
+int msnap_formation_collide_t_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
+                                     const double *pos_rows_t, const double *pos_rows, const double *pos_cols,
+                                     double radius, double *min_dist, int32_t *partner, int32_t *hit) {
+  if (!ctx || n_rows < 0 || n_cols < 0 || n_samples < 1 || row_offset < 0 || !(radius >= 0.0))
+    return MSNAP_EINVAL;
+  if (n_rows == 0) return MSNAP_OK;
+  if (!pos_rows_t || !pos_rows || (n_cols > 0 && !pos_cols) || !min_dist || !partner || !hit) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  return launch_formation_collide(ctx, n_rows, row_offset, n_cols, n_samples, pos_rows, pos_cols, radius,
+                                  min_dist, partner, hit, pos_rows_t);
 }
 
 int msnap_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
@@ -687,9 +717,17 @@ int msnap_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_co
   MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[0].p, pos_rows, b_rows, hipMemcpyHostToDevice, ctx->stream));
   if (b_cols)
     MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[1].p, pos_cols, b_cols, hipMemcpyHostToDevice, ctx->stream));
+  // The once-per-pair evaluation credits column-side minima to the ROW drones, which is only right when
+  // pos_rows is the slice [row_offset, row_offset + n_rows) of pos_cols.  Host arrays can be compared: a
+  // caller whose rows are some other set of drones gets the one-sided evaluation instead of wrong partners.
+  const int saved_no_sym = ctx->collide_no_sym;
+  if ((long long)row_offset + n_rows <= n_cols && pos_rows != pos_cols + (size_t)row_offset * n_samples * 3 &&
+      memcmp(pos_rows, pos_cols + (size_t)row_offset * n_samples * 3, b_rows) != 0)
+    ctx->collide_no_sym = 1;
   rc = launch_formation_collide(ctx, n_rows, row_offset, n_cols, n_samples, (const double *)ctx->stage[0].p,
                                 (const double *)ctx->stage[1].p, radius, (double *)ctx->stage[2].p,
-                                (int32_t *)ctx->stage[3].p, (int32_t *)ctx->stage[4].p);
+                                (int32_t *)ctx->stage[3].p, (int32_t *)ctx->stage[4].p, nullptr);
+  ctx->collide_no_sym = saved_no_sym;
   if (rc) return rc;
   MSNAP_HIP(ctx, hipMemcpyAsync(min_dist, ctx->stage[2].p, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   MSNAP_HIP(ctx, hipMemcpyAsync(partner, ctx->stage[3].p, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));

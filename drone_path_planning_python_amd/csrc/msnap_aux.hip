@@ -141,6 +141,10 @@ int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const
 // running sum of durations, last piece extrapolates; Horner of :17-22 with
 // separate multiply and add, hence fp contract off for bit parity)
 // ------------------------------------------------------------------------------------
+constexpr int kRowBlockRows = 128;   // rows per row block of the pairwise pass (kRowBlock below): pitch granularity of its row image
+__global__ void collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t,
+                                         int ny, int32_t *__restrict__ fill, size_t fill_n);
+
 // Generic form: one thread per (drone, sample), the reference's search loop as it stands.  Used for
 // drones whose durations are not all >= 0 (the search is then not a partition into ranges), for
 // dt == 0 and for paths whose samples do not fit the LDS image of the fast kernel.
@@ -197,7 +201,7 @@ sample_generic_kernel(const double *__restrict__ coef, const double *__restrict_
 template <int NC>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
-              int naxes, int DW, double *__restrict__ pos) {
+              int naxes, int DW, double *__restrict__ pos, double *__restrict__ pos_t, int Rp) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sB = smem;                                    // [DW][M + 1] running sums, b_0 = 0
@@ -274,12 +278,24 @@ sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, d
     } else {
       for (size_t e = tid; e < words; e += blockDim.x) out[e] = sImg[e];
     }
+    // second output for the pairwise pass (msnap_sample_collide): the same samples as the transposed row image
+    // [sample][xyz][row] (row pitch Rp) that collide_span_kernel reads -- the workgroup's DW drones are DW
+    // consecutive rows, so every (sample, axis) is one run of DW doubles -- instead of a transposition pass
+    // over the finished positions
+    if (pos_t != nullptr) {
+      const int runs = (int)per_drone;              // (sample, axis) pairs; naxes == 3 (checked by the launcher)
+      for (int e = tid; e < runs * nd; e += blockDim.x) {
+        const int sk = e / nd, dl = e - sk * nd;
+        pos_t[(size_t)sk * Rp + d0 + dl] = sImg[(size_t)dl * per_drone + sk];
+      }
+    }
     __syncthreads();
   }
 }
 
 int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
-                  int n_samples, int n_axes, double *pos) {
+                  int n_samples, int n_axes, double *pos, double *pos_t) {
+  const int Rp = (n_drones + kRowBlockRows - 1) / kRowBlockRows * kRowBlockRows;
   // drones per workgroup: about 256 (piece, axis) threads, within 48 KB of LDS image
   const size_t img_per_drone = (size_t)n_samples * n_axes * sizeof(double);
   int dw = 256 / (n_seg * n_axes);
@@ -293,10 +309,10 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
     if (blocks > (size_t)ctx->n_cu * 64) blocks = (size_t)ctx->n_cu * 64;
     if (ctx->order == 7)
       hipLaunchKernelGGL((sample_kernel<8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
-                         n_drones, n_seg, n_samples, n_axes, dw, pos);
+                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp);
     else
       hipLaunchKernelGGL((sample_kernel<10>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
-                         n_drones, n_seg, n_samples, n_axes, dw, pos);
+                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp);
   } else {
     // one drone's samples exceed the image: the (drone, sample) form
     const size_t total = (size_t)n_drones * n_samples;
@@ -308,6 +324,12 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
     else
       hipLaunchKernelGGL((sample_generic_kernel<10>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, coef, dur, dt,
                          n_drones, n_seg, n_samples, n_axes, pos);
+    if (pos_t != nullptr) {     // paths too long for the image: the transposition pass after all
+      MSNAP_HIP(ctx, hipGetLastError());
+      const int E = n_samples * 3;
+      hipLaunchKernelGGL(collide_transpose_kernel, dim3(Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream,
+                         (const double *)pos, n_drones, Rp, E, pos_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
+    }
   }
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
@@ -515,6 +537,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 // ------------------------------------------------------------------------------------
 constexpr int kRowsPerLane = 2;   // (3 rows x 4-column blocks, 165 VGPRs, 3 waves per SIMD: 4096 x 91 in 346 us against 230)
 constexpr int kRowBlock = kWave * kRowsPerLane;
+static_assert(kRowBlock == kRowBlockRows, "the sampler's row image uses the pairwise pass's row pitch");
 constexpr int kColBlock = 8;      // column drones whose running minima a lane keeps in registers (per row)
 constexpr int kSampleChunk = 6;   // samples per scalar fetch
 
@@ -1024,9 +1047,11 @@ __global__ void __launch_bounds__(256) collide_part_clear_kernel(double *__restr
   }
 }
 
+// `rows_t`: the rows' transposed image [n_samples][3][row pitch] when the caller already has it (the sampler's
+// second output, msnap_sample_collide); nullptr: built here from pos_rows
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                              const double *pos_rows, const double *pos_cols, double radius, double *min_dist,
-                             int32_t *partner, int32_t *hit) {
+                             int32_t *partner, int32_t *hit, const double *rows_t_in) {
   CollideGeom g;
   g.R = n_rows;
   g.ro = row_offset;
@@ -1065,7 +1090,11 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.os = rows_in_cols ? row_offset : n_cols;
   g.oe = rows_in_cols ? row_offset + n_rows : n_cols;
   const size_t cpart_entries = (size_t)g.n_rb * n_rows;
-  g.sym = (rows_in_cols && n_rows > kRowBlock && cpart_entries * 12 <= ((size_t)256 << 20)) ? 1 : 0;
+  // (the column-side partial buffer is bounded at 2 GB: 170 k rows on one GPU; beyond that, and for callers whose
+  // rows are not the slice of the columns -- "collide_no_sym" -- every pair of the range is evaluated from both
+  // sides; msnap_get_option("collide_last_sym") reports which way the last pass went)
+  g.sym = (rows_in_cols && n_rows > kRowBlock && !ctx->collide_no_sym && cpart_entries * 12 <= ((size_t)2 << 30)) ? 1 : 0;
+  ctx->collide_last_sym = g.sym;
   g.upw = 1;
   g.total = collide_ustart(g, g.n_rb);
   // Equal contiguous shares of the line, one 8-column block (x 128 rows) each.  Many small shares beat one
@@ -1118,7 +1147,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   const size_t part_entries = ((size_t)waves + g.n_rb) * g.sparts * kRowBlock;
   const size_t centries = g.sym ? cpart_entries * g.sparts : 0;
   const int E = n_samples * 3;
-  const size_t t_entries = (size_t)g.Rp * E;
+  const size_t t_entries = rows_t_in ? 0 : (size_t)g.Rp * E;
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
@@ -1127,11 +1156,13 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   double *cd = pd + part_entries;
   int32_t *pj = (int32_t *)(cd + centries);
   int32_t *ci = pj + part_entries;
-  hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
-                     n_rows, g.Rp, E, rows_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
-  MSNAP_HIP(ctx, hipGetLastError());
+  if (!rows_t_in) {
+    hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
+                       n_rows, g.Rp, E, rows_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
+    MSNAP_HIP(ctx, hipGetLastError());
+  }
   hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
-                     (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
+                     rows_t_in ? rows_t_in : (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);
@@ -1326,6 +1357,20 @@ __device__ __forceinline__ double wave_minmax_f64(double v) {
 }
 __device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
 __device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
+// The same butterflies with IEEE minNum / maxNum: a NaN operand is ignored, so a wave that mixes NaN and finite
+// values ends with the extreme of the finite ones in EVERY lane (with the compare-and-select fold a lane holding
+// NaN keeps it and its partner drops that subtree: the lanes would disagree); all-NaN stays NaN.
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_num_f64(double v) {
+  auto fold = [](double a, double b) { return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b); };
+  v = fold(v, dpp_f64<0xB1>(v));
+  v = fold(v, dpp_f64<0x4E>(v));
+  v = fold(v, dpp_f64<0x141>(v));
+  v = fold(v, dpp_f64<0x140>(v));
+  v = fold(v, __shfl_xor(v, 16));
+  v = fold(v, __shfl_xor(v, 32));
+  return v;
+}
 
 // the value of lane 0 as a compiler-visible wave-uniform value (after a wave reduction every lane holds
 // the same number, but only this makes the branches and triangle loads that depend on it scalar)
@@ -1371,9 +1416,16 @@ mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__
     const int s = s0 + lane;
     const double *p = pos + ((size_t)d * S + (s < S ? s : S - 1)) * 3;   // lanes past the end replay the last sample
     const double px = p[0], py = p[1], pz = p[2];
+    // the box of the wave's FINITE samples, wave-uniform (non-finite samples never win a minimum, include/msnap.h:
+    // they must not distort the cull of the finite ones either; a stretch without a finite coordinate gives a
+    // NaN box, whose bound is 0 for every triangle: nothing is culled, nothing can win)
     double lo[3], hi[3];
-    lo[0] = wave_min_f64(px); lo[1] = wave_min_f64(py); lo[2] = wave_min_f64(pz);
-    hi[0] = wave_max_f64(px); hi[1] = wave_max_f64(py); hi[2] = wave_max_f64(pz);
+    const double fx = __builtin_isfinite(px) ? px : __builtin_nan(""), fy = __builtin_isfinite(py) ? py : __builtin_nan(""),
+                 fz = __builtin_isfinite(pz) ? pz : __builtin_nan("");
+    lo[0] = uniform_f64(wave_minmax_num_f64<false>(fx)); lo[1] = uniform_f64(wave_minmax_num_f64<false>(fy));
+    lo[2] = uniform_f64(wave_minmax_num_f64<false>(fz));
+    hi[0] = uniform_f64(wave_minmax_num_f64<true>(fx)); hi[1] = uniform_f64(wave_minmax_num_f64<true>(fy));
+    hi[2] = uniform_f64(wave_minmax_num_f64<true>(fz));
     double wbest = uniform_f64(wave_min_f64(best));            // wave-uniform bound: min over the lanes so far
     for (int t0 = 0; t0 < n_tris; t0 += kWave) {
       const int tl = t0 + lane;

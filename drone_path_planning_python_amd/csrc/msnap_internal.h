@@ -80,6 +80,8 @@ struct msnap_ctx {
   void *mesh_tests = nullptr;   // "mesh_count_tests": device counter of the point-triangle tests evaluated (not culled)
   int collide_waves_per_cu = 0; // "collide_waves_per_cu": shares per CU of the pairwise pass (0: one column block per share)
   int collide_sample_parts = 0; // "collide_sample_parts": waves per share of the pairwise pass (0: chosen per launch)
+  int collide_no_sym = 0;       // "collide_no_sym": 1 = the rows of msnap_formation_collide are NOT the slice of the columns at row_offset: one-sided evaluation
+  int collide_last_sym = 0;     // "collide_last_sym" (read): 1 if the last msnap_formation_collide evaluated its own-range pairs once
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
   char hip_err[256] = {0};
   char last_kernel[96] = {0};   // msnap_last_kernel: the solve kernel instance the last solve entry point launched
@@ -107,13 +109,13 @@ int launch_pack(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, con
 int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const double *rb_pose,
                                const double *offsets, double *out);
 int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
-                  double dt, int n_samples, int n_axes, double *pos);
+                  double dt, int n_samples, int n_axes, double *pos, double *pos_t);
 int launch_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
                      int n_samples, const double *ts, double *out);
 int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double *cost);
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                              const double *pos_rows, const double *pos_cols, double radius,
-                             double *min_dist, int32_t *partner, int32_t *hit);
+                             double *min_dist, int32_t *partner, int32_t *hit, const double *rows_t);
 int launch_formation_collide_part(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all, int part,
                                   int n_parts, double *out_d2, int32_t *out_j);
 int launch_formation_collide_finish(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts, size_t part_stride,

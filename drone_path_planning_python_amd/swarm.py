@@ -82,11 +82,15 @@ class DeviceCompute:
         torch = self.torch
         n, m, _ = wp.shape
         M = m - 1
+        # msnap_solve_grid_device takes no segment count: it writes n x (segments of the PREPARED grid) blocks.
+        # A batch with another waypoint count would be read and written past its buffers.
+        if wp.dim() != 3 or wp.shape[2] != 4 or m != self.ctx.grid_waypoints():
+            raise ValueError(f"solve_grid: wp must be [n, {self.ctx.grid_waypoints()}, 4] for the prepared grid, got {tuple(wp.shape)}")
         coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
         dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         if n:
-            self.ctx.solve_grid_device(n, wp, coef, dur, status)
+            self.ctx.solve_grid_device(n, wp, coef, dur, status, n_seg=M)
         return coef, dur, status
 
     def sample(self, coef, dur, dt, n_samples):
@@ -97,13 +101,27 @@ class DeviceCompute:
             self.ctx.sample_device(n, M, coef, dur, dt, n_samples, 3, pos)
         return pos
 
-    def collide(self, pos_rows, row_offset, pos_all, radius):
+    def sample_rows_t(self, coef, dur, dt, n_samples):
+        """(pos [n, S, 3], pos_t): the sampler's second output is the transposed row image [S][3][pitch] the
+        pairwise pass reads -- `collide(..., rows_t=pos_t)` then skips its own transposition pass."""
+        torch = self.torch
+        n, M = dur.shape
+        pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
+        pos_t = torch.empty((self.ctx.collide_rows_t_doubles(n, n_samples),), dtype=torch.float64, device=self.device)
+        if n:
+            self.ctx.sample_collide_device(n, M, coef, dur, dt, n_samples, pos, pos_t)
+        return pos, pos_t
+
+    def collide(self, pos_rows, row_offset, pos_all, radius, rows_t=None):
         torch = self.torch
         r = pos_rows.shape[0]
         md = torch.empty((r,), dtype=torch.float64, device=self.device)
         partner = torch.empty((r,), dtype=torch.int32, device=self.device)
         hit = torch.empty((r,), dtype=torch.int32, device=self.device)
-        if r:
+        if r and rows_t is not None:
+            self.ctx.formation_collide_t_device(r, row_offset, pos_all.shape[0], pos_rows.shape[1], rows_t, pos_rows,
+                                                pos_all, radius, md, partner, hit)
+        elif r:
             self.ctx.formation_collide_device(r, row_offset, pos_all.shape[0], pos_rows.shape[1], pos_rows,
                                               pos_all, radius, md, partner, hit)
         return md, partner, hit
@@ -242,7 +260,11 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
     if status_local is not None and int(abs(status_local).sum()) != 0:
         raise ValueError("formation_pass: the solve reported failed drones (status != 0) in rows "
                          f"[{lo}, {hi}); their samples are NaN and cannot be collision-checked")
-    pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
+    rows_t = None
+    if world == 1 and hasattr(compute, "sample_rows_t"):
+        pos_local, rows_t = compute.sample_rows_t(coef_local, dur_local, dt, n_samples)
+    else:
+        pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
     overlapped = mesh_tris is not None and hasattr(compute, "mesh_begin")
     if overlapped:
         compute.mesh_begin(pos_local, mesh_tris, radius)
@@ -254,7 +276,10 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
             md, partner, hit = compute.collide_finish(parts, n_total, lo, hi - lo, radius)
         else:
             pos_all = pos_local
-            md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)
+            if rows_t is not None:
+                md, partner, hit = compute.collide(pos_local, lo, pos_all, radius, rows_t=rows_t)
+            else:
+                md, partner, hit = compute.collide(pos_local, lo, pos_all, radius)
         mmd = mhit = None
         if overlapped:
             mmd, mhit = compute.mesh_end()

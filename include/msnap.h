@@ -93,6 +93,9 @@ int msnap_host_free(void *ptr);
  *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 8-column x 128-row block per share)
  *   "collide_sample_parts" waves per share of the pairwise pass, each a range of the sample chunks
  *                          (0 = chosen per launch: more than one only when the launch is small)
+ *   "collide_no_sym"       1: the rows handed to msnap_formation_collide are not the slice of its columns at
+ *                          row_offset -- every pair is evaluated one-sidedly (read-only companion
+ *                          "collide_last_sym": 1 if the last pass evaluated its own-range pairs once)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
@@ -211,7 +214,9 @@ int msnap_snap_cost_device(msnap_ctx *ctx, int n_drones, int n_seg, const double
  *   partner  [n_rows]  lowest global j attaining it (-1 if none)
  *   hit      [n_rows]  min_dist < 2*radius
  * pos_rows must be the rows [row_offset, row_offset + n_rows) of pos_cols (the same samples):
- * pairs inside that range are evaluated once and credited to both drones.
+ * pairs inside that range are evaluated once and credited to both drones.  The host-pointer entry
+ * compares the two arrays and falls back to the one-sided evaluation when they differ; a device-pointer
+ * caller whose rows are some other set of drones sets the option "collide_no_sym" first.
  * n_cols == 0 gives (+inf, -1, 0).
  * Non-finite samples never win a minimum (IEEE minNum): a drone whose samples are NaN -- the
  * output of a solve with status != 0 -- reports (+inf, -1, 0) and is invisible to the other
@@ -226,6 +231,20 @@ int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, i
                                    int n_samples, const double *pos_rows,
                                    const double *pos_cols, double radius,
                                    double *min_dist, int32_t *partner, int32_t *hit);
+
+/* The same pass for a caller that already holds the rows' TRANSPOSED image -- what msnap_sample_collide_device
+ * writes next to the positions: pos_rows_t [n_samples][3][P], P = n_rows rounded up to whole 128-row blocks
+ * (msnap_collide_rows_t_doubles(n_rows, n_samples) doubles in all; the rows behind n_rows are never credited).
+ * The pass reads its rows from that image (512 contiguous bytes per wave and load); given it, it skips its own
+ * transposition pass over pos_rows.  Device pointers only: the pair exists to keep the formation pipeline
+ * (sampler -> pairwise pass) on the GPU without the intermediate pass. */
+size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples);
+int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
+                                const double *dur, double dt, int n_samples, double *pos, double *pos_t);
+int msnap_formation_collide_t_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
+                                     int n_samples, const double *pos_rows_t, const double *pos_rows,
+                                     const double *pos_cols, double radius, double *min_dist,
+                                     int32_t *partner, int32_t *hit);
 
 /* ---- the same pass split over the ranks of a job: every unordered pair on exactly ONE rank --------
  * BASELINE.json north_star: "the drone batch shards across the 8 GPUs ... with an RCCL all-gather for the

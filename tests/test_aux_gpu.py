@@ -598,3 +598,91 @@ def test_examples_run(script):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", script)], check=True, capture_output=True,
                          text=True, timeout=300).stdout
     assert len(out.splitlines()) >= 3
+
+
+@pytest.mark.parametrize("n,m,S", [(70, 8, 40), (300, 10, 91), (129, 20, 96), (5, 3, 7), (260, 6, 300)])
+def test_sampler_row_image_feeds_the_pairwise_pass(ctx7, n, m, S):
+    """msnap_sample_collide_device: the positions are the sampler's, bit for bit, and its second output IS the
+    transposed row image [S][3][pitch] (incl. paths too long for the LDS image: 300 samples); the pairwise
+    pass run from that image equals the pass that transposes by itself, the host-pointer entry and the oracle."""
+    import torch
+    import c_oracle
+    from drone_path_planning_python_amd import swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(700 + n, n, m)
+    wp[..., :3] *= 0.3
+    comp = sw.DeviceCompute(ctx7, torch)
+    try:
+        coef, dur, status = comp.solve(torch.from_numpy(wp).cuda(), torch.from_numpy(t).cuda())
+        assert int(status.abs().sum().item()) == 0
+        pos = comp.sample(coef, dur, 0.1, S)
+        pos2, pos_t = comp.sample_rows_t(coef, dur, 0.1, S)
+        np.testing.assert_array_equal(pos2.cpu().numpy(), pos.cpu().numpy())
+        pitch = (n + 127) // 128 * 128
+        img = pos_t.cpu().numpy().reshape(S, 3, pitch)
+        np.testing.assert_array_equal(img[:, :, :n], pos.cpu().numpy().transpose(1, 2, 0))
+        a = comp.collide(pos, 0, pos, 0.2)
+        b = comp.collide(pos2, 0, pos2, 0.2, rows_t=pos_t)
+        ref = c_oracle.formation_collide(pos.cpu().numpy(), 0.2)
+        for x, y, z in zip(a, b, ref):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+            np.testing.assert_array_equal(y.cpu().numpy().astype(z.dtype), z)
+        res = sw.formation_pass(comp, coef, dur, n, 1, 0, 0.1, S, 0.2, torch=torch)      # takes the row-image route
+        np.testing.assert_array_equal(res.min_dist.cpu().numpy(), ref[0])
+        np.testing.assert_array_equal(res.partner.cpu().numpy(), ref[1])
+    finally:
+        torch.cuda.synchronize()
+        ctx7.use_own_stream()
+
+
+def test_collide_rows_that_are_not_the_slice_of_the_columns(ctx7):
+    """include/msnap.h: the once-per-pair evaluation assumes pos_rows == pos_cols[row_offset : row_offset + n_rows].
+    The host-pointer entry compares the arrays and evaluates one-sidedly when they differ (device callers set
+    "collide_no_sym"); either way the rows' minima against the given columns must be exact."""
+    rng = np.random.default_rng(77)
+    cols = rng.uniform(-3, 3, size=(400, 30, 3))
+    rows = rng.uniform(-3, 3, size=(300, 30, 3))              # NOT cols[50:350]
+    md, partner, hit = ctx7.formation_collide(rows, cols, 0.25, row_offset=50)
+    assert ctx7.get_option("collide_last_sym") == 0
+    d2 = np.full((300, 400), np.inf)
+    for j in range(400):
+        d = cols[j][None] - rows
+        d2[:, j] = np.fmin.reduce(O.fma_square(d[..., 2], O.fma_square(d[..., 1], d[..., 0] * d[..., 0])), axis=1)
+    d2[np.arange(300), 50 + np.arange(300)] = np.inf        # a row never meets the column of its own global index
+    np.testing.assert_array_equal(md, np.sqrt(d2.min(axis=1)))
+    np.testing.assert_array_equal(partner, d2.argmin(axis=1))
+    # the aliased call takes the symmetric route again
+    ctx7.formation_collide(cols[50:350], cols, 0.25, row_offset=50)
+    assert ctx7.get_option("collide_last_sym") == 1
+
+
+def test_mesh_sweep_with_partially_nonfinite_paths(ctx7):
+    """A 64-sample stretch that mixes NaN / inf and finite samples (e.g. Horner overflow late in a path): the
+    non-finite samples never win a minimum, and they must not distort the cull of the finite ones -- the
+    bounding box of the stretch is built from the finite samples only.  Against the C oracle on the
+    reference's wall scene, with the finite samples on both sides of the non-finite ones."""
+    import c_oracle
+    from drone_path_planning_python_amd import stl
+    tris = np.concatenate([stl.load_stl(os.path.join(GOLDEN_DIR, "env-scene-hole.stl")),
+                           stl.load_stl(os.path.join(GOLDEN_DIR, "env-scene-ltu-experiment.stl"))])
+    rng = np.random.default_rng(5)
+    n, S = 48, 96
+    start = rng.uniform([-6, -8, -2], [6, -3, 3], size=(n, 1, 3))
+    pos = start + np.linspace(0, 1, S)[None, :, None] * rng.uniform([-2, 8, -1], [2, 14, 1], size=(n, 1, 3))
+    for d in range(n):
+        k = d % 6
+        if k == 0:
+            pos[d, 5:40] = np.nan                       # a NaN stretch inside the first wave
+        elif k == 1:
+            pos[d, ::2, 1] = np.nan                     # every other sample, one coordinate
+        elif k == 2:
+            pos[d, 60:] = np.inf                        # overflow late in the path
+        elif k == 3:
+            pos[d, :64] = np.nan                        # the whole first wave
+        elif k == 4:
+            pos[d] = np.nan                             # a failed drone
+    md, hit = ctx7.mesh_sweep(pos, tris, 0.3)
+    rmd, rhit = c_oracle.mesh_sweep(pos, tris, 0.3)
+    np.testing.assert_allclose(md, rmd, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(hit, rhit)
+    assert np.isinf(md[4]) and not hit[4] and hit.any()

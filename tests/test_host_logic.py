@@ -239,3 +239,38 @@ def test_fma_square_is_exactly_rounded():
     pos[:30] = np.round(pos[:30] * 2) / 2
     for a, b in zip(O.formation_collide(pos, 0.3), c_oracle.formation_collide(pos, 0.3)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_device_solve_grid_refuses_batches_that_do_not_match_the_prepared_grid():
+    """msnap_solve_grid_device takes no segment count: it writes n x (segments of the prepared grid) blocks.  The
+    device wrappers must refuse a batch sized for another grid before anything is launched (no GPU needed: the
+    context is a stand-in that counts launches)."""
+    import threading
+    import torch
+    from drone_path_planning_python_amd import Context, swarm
+
+    class FakeCtx:
+        ncoef = 8
+        launches = 0
+
+        def grid_waypoints(self):
+            return 11
+
+        def solve_grid_device(self, n, wp, coef, dur, status, n_seg=None):
+            assert n_seg == 10 and tuple(coef.shape) == (n, 10, 4, 8)
+            self.launches += 1
+
+    comp = object.__new__(swarm.DeviceCompute)
+    comp.ctx, comp.torch, comp.device = FakeCtx(), torch, torch.device("cpu")
+    with pytest.raises(ValueError):
+        comp.solve_grid(torch.zeros((4, 21, 4), dtype=torch.float64))      # 20 segments on a 10-segment grid
+    with pytest.raises(ValueError):
+        comp.solve_grid(torch.zeros((4, 11, 3), dtype=torch.float64))
+    assert comp.ctx.launches == 0
+    comp.solve_grid(torch.zeros((4, 11, 4), dtype=torch.float64))
+    assert comp.ctx.launches == 1
+    # and the Context-level wrapper: buffers sized for another segment count than the prepared grid
+    ctx = object.__new__(Context)
+    ctx._grid_m, ctx._lock = 11, threading.Lock()
+    with pytest.raises(ValueError):
+        ctx.solve_grid_device(4, 0, 0, 0, 0, n_seg=20)
