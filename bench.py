@@ -61,6 +61,7 @@ VALU_F64_OPS = 256 * 4 * 16 * 2.4e9
 XGMI_LINK_GBS = 153.0          # per link and direction; 7 links per GPU (full mesh)
 PAIR_OPS = 7                   # vector instructions per pair and sample: 3 differences, 1 product, 2 FMAs, 1 minimum
 PAIR_FLOPS = 9                 # the same as floating-point operations (an FMA counts two)
+MESH_TEST_OPS = 82             # fp64 vector operations of one full point-triangle closest-point evaluation (pt_tri_d2)
 PAIR_MIX_ATTAINABLE = 0.897    # the 7-instruction mix alone, 4 waves per SIMD: 4.46 nominal cycles per wave-instruction
                                # (tools/micro/f64_rate_micro.hip: the SIMDs run at ~2.15 GHz under sustained fp64 load)
 
@@ -75,29 +76,48 @@ def sampler_bytes(n_drones: int, n_seg: int, order: int, n_samples: int) -> int:
     return n_drones * 8 * (n_seg * (3 * (order + 1) + 1) + 3 * n_samples)
 
 
-def pmc_traffic(n_drones: int, n_seg: int, order: int):
-    """(HBM bytes per launch, kernel name) of the solve at this workload, from the committed PMC
-    passes (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X: separate
-    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950
-    correction).  (None, None) when no matching profile exists."""
+def built_csrc_sha():
+    from drone_path_planning_python_amd._lib import csrc_sha
+    return csrc_sha()
+
+
+def pmc_traffic(n_drones: int, n_seg: int, order: int, kernel: str = None):
+    """(HBM bytes per launch, source note) of the solve at this workload from the committed PMC passes
+    (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X: separate FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  The counters are only quoted when
+    they were taken from the kernel sources this run was built from (csrc_sha) and, if `kernel` is given, from the
+    kernel instance this run launched; otherwise the bytes are None and the note says why."""
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(tp) as f:
             rec = json.load(f)
-        ent = rec.get(f"{n_drones}x{n_seg}o{order}") or {}
-        return ent.get("hbm_bytes_per_launch"), ent.get("kernel")
     except Exception:
-        return None, None
+        return None, "no profiles/pmc_traffic.json"
+    ent = rec.get(f"{n_drones}x{n_seg}o{order}")
+    if not ent:
+        return None, "profiles/pmc_traffic.json holds no pass for this workload"
+    sha = built_csrc_sha()
+    if ent.get("csrc_sha") != sha:
+        return None, (f"profiles/pmc_traffic.json was taken from csrc {ent.get('csrc_sha', 'unrecorded')}, this build is "
+                      f"{sha}: stale counters are not quoted (tools/make_profiles.sh renews them)")
+    if kernel and ent.get("kernel") != kernel:
+        return None, f"profiles/pmc_traffic.json measured {ent.get('kernel')}, this run launched {kernel}"
+    return ent.get("hbm_bytes_per_launch"), f"profiles/pmc_traffic.json, csrc {sha}, {ent.get('kernel')}"
 
 
 def pmc_counter(kernel: str, counter: str):
-    """Mean per launch of a PMC counter of one kernel on the bench's own workload, from the committed
-    passes (profiles/pmc_counters.json, tools/make_profiles.sh); None when absent."""
+    """(mean per launch of a PMC counter of one kernel on the bench's own workload, source note) from the committed
+    passes (profiles/pmc_counters.json, tools/make_pipeline_profile.sh); None unless taken from this build's sources."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_counters.json")) as f:
-            return json.load(f).get(kernel, {}).get(counter)
+            rec = json.load(f)
     except Exception:
-        return None
+        return None, "no profiles/pmc_counters.json"
+    sha = built_csrc_sha()
+    if rec.get("csrc_sha") != sha:
+        return None, (f"profiles/pmc_counters.json was taken from csrc {rec.get('csrc_sha', 'unrecorded')}, this build is "
+                      f"{sha}: not quoted")
+    return rec.get(kernel, {}).get(counter), f"profiles/pmc_counters.json, csrc {sha}"
 
 
 def parse():
@@ -115,6 +135,7 @@ def parse():
     ap.add_argument("--no-shared-grid", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-config pipelines")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling legs (65536 x 10 order 7, 16384-drone formation)")
     ap.add_argument("--saturated-drones", type=int, default=1 << 20)
     ap.add_argument("--config-reps", type=int, default=0, help="timed repetitions per config pipeline (0: from --steps)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
@@ -334,13 +355,16 @@ def sum_over_ranks(torch, dist, values, device, use_pg):
     return [int(x) for x in tv.tolist()]
 
 
-def run_formation_config(cfg, env, reps, warm):
-    """configs[2] (cfg = 2) / configs[3] (cfg = 3): solve -> sample -> all-gather -> pairwise pass
-    (-> mesh sweep), 4096 drones sharded by drone.  Returns the report dict (rank 0) or None."""
+def run_formation_config(cfg, env, reps, warm, n_groups=512):
+    """configs[2] (cfg = 2) / configs[3] (cfg = 3): solve -> sample -> [all-gather ->] pairwise pass
+    [-> all-gather of the partial minima -> fold] (-> mesh sweep), n_groups x 8 drones (4096 at the default)
+    sharded by drone.  One rank: one symmetric launch over the whole swarm, fed by the sampler's row image.
+    Several ranks: every unordered pair on exactly one rank (msnap_formation_collide_part), two collectives.
+    Returns the report dict (rank 0) or None."""
     torch, dist, ctx, device = env["torch"], env["dist"], env["ctx7"], env["device"]
     rank, world, use_pg, coll, red_dev = env["rank"], env["world"], env["use_pg"], env["coll"], env["red_dev"]
     from drone_path_planning_python_amd import stl, swarm, synthetic
-    rb, off, t = synthetic.formation_config(cfg)
+    rb, off, t = synthetic.formation_config(cfg, n_groups)
     G, m, _ = rb.shape
     M, N, order = m - 1, G * off.shape[0], 7
     # inputs through a8 on the GPU (untimed: the producer of the waypoints, not the path being timed)
@@ -360,7 +384,8 @@ def run_formation_config(cfg, env, reps, warm):
     comp = swarm.DeviceCompute(ctx, torch, side_ctx=side_ctx)
     twp = torch.from_numpy(np.ascontiguousarray(wp[lo:hi])).to(device)
     tt = torch.from_numpy(t).to(device)
-    stage_names = ["solve", "sample"] + (["allgather"] if world > 1 else []) + ["pairwise"] + (["mesh"] if cfg == 3 else [])
+    stage_names = ["solve", "sample"] + (["allgather", "pairwise", "allgather_parts", "fold"] if world > 1 else ["pairwise"]) + \
+        (["mesh"] if cfg == 3 else [])
     nst = len(stage_names)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
 
@@ -377,20 +402,32 @@ def run_formation_config(cfg, env, reps, warm):
         mark()
         coef, dur, status = comp.solve_grid(twp)      # the swarm shares the reference's uniform grid: K2
         mark()
-        pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
+        rows_t = None
+        if world == 1:      # the sampler also writes the transposed row image the pairwise pass reads
+            pos, rows_t = comp.sample_rows_t(coef, dur, synthetic.SAMPLE_DT, S)
+        else:
+            pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
         mark()
-        if tris is not None and overlap:
-            comp.mesh_begin(pos, tris, synthetic.DRONE_RADIUS)
-        pos_all = pos
-        if world > 1:
-            pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch)
+        try:
+            if tris is not None and overlap:
+                comp.mesh_begin(pos, tris, synthetic.DRONE_RADIUS)
+            if world > 1:
+                pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch)
+                mark()
+                part = comp.collide_part(pos_all, rank, world)        # this rank's share of the swarm's pairs
+                mark()
+                parts = swarm.all_gather_parts(part, world, coll, torch)
+                mark()
+                md, partner, hit = comp.collide_finish(parts, N, lo, n, synthetic.DRONE_RADIUS)
+            else:
+                md, partner, hit = comp.collide(pos, lo, pos, synthetic.DRONE_RADIUS, rows_t=rows_t)
             mark()
-        md, partner, hit = comp.collide(pos, lo, pos_all, synthetic.DRONE_RADIUS)
-        mark()
-        mh = None
-        if tris is not None:
-            _, mh = comp.mesh_end() if overlap else comp.mesh(pos, tris, synthetic.DRONE_RADIUS)
-            mark()
+            mh = None
+            if tris is not None:
+                _, mh = comp.mesh_end() if overlap else comp.mesh(pos, tris, synthetic.DRONE_RADIUS)
+                mark()
+        finally:
+            comp.mesh_abort()       # joins the side stream if something above raised between begin and end
         return status, hit, mh, md, pos
 
     def timed(overlap, recs):
@@ -415,11 +452,10 @@ def run_formation_config(cfg, env, reps, warm):
     grid_kernel = ctx.last_kernel()     # what the library launched for the shared-grid solve (msnap_last_kernel)
     # median over the repetitions: one preempted launch must not pass for a stage's time
     stage_us = [float(np.median([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)])) * 1e3 for k in range(nst)]
-    # pass 2 (configs[3]): the pipeline as it is run, the mesh sweep beside the exchange and the pairwise pass
+    # pass 2: the pipeline as it is run -- no events between the stages, and (configs[3]) the mesh sweep beside the
+    # exchanges and the pairwise pass
     wall_serial = wall
-    if tris is not None:
-        wall, (status, hit, mh, md, pos_keep) = timed(True, None)
-        side_ctx.close()
+    wall, (status, hit, mh, md, pos_keep) = timed(tris is not None, None)
     # the per-drone-grid kernel (K1: any time grids) on the same shard, outside the pipeline
     for _ in range(3):
         comp.solve(twp, tt)
@@ -431,6 +467,17 @@ def run_formation_config(cfg, env, reps, warm):
     torch.cuda.synchronize()
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
     k1_kernel = ctx.last_kernel()
+    mesh_extra = None
+    if cfg == 3:
+        # how many point-triangle tests the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
+        ctx.set_option("mesh_count_tests", 1)
+        comp.mesh(pos_keep, tris, synthetic.DRONE_RADIUS)
+        mesh_extra = ctx.get_option("mesh_count_tests")
+        ctx.set_option("mesh_count_tests", 0)
+    torch.cuda.synchronize()
+    comp.close()                 # drops the wrapper of the side stream before its context goes
+    if side_ctx is not None:
+        side_ctx.close()
     mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial], red_dev, use_pg)
     cnt = sum_over_ranks(torch, dist, [int(status.abs().sum().item()), int(hit.sum().item()),
                                        int(mh.sum().item()) if mh is not None else 0], red_dev, use_pg)
@@ -438,11 +485,12 @@ def run_formation_config(cfg, env, reps, warm):
         return None
     wall_max, st, gemm, wall_serial_max = mx[0], dict(zip(stage_names, mx[1:1 + nst])), mx[1 + nst], mx[2 + nst]
     per = wall_max / reps
-    fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz"))
+    fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz")) if n_groups == 512 else None
     n_max = max(swarm.shard_sizes(N, world))
     pair_alg = N * (N - 1) / 2 * S * PAIR_OPS                 # every unordered pair once
-    # what the largest shard evaluates: its rows against the other shards' columns, its own block once per pair
-    pair_exec = (n_max * (N - n_max) + n_max * (n_max + 127) / 2) * S * PAIR_OPS
+    # what a rank evaluates: 1 / world of the swarm's (128-row block, column) units, each pair of them once; inside the
+    # diagonal blocks both orders of a pair are computed (a 128 x 128 block instead of its triangle)
+    pair_exec = (N * (N - 1) / 2 + 64.0 * N) / world * S * PAIR_OPS
     rep = {
         "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
@@ -451,11 +499,12 @@ def run_formation_config(cfg, env, reps, warm):
         "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling)", "rccl_ranks": world,
         "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": st,
-        "stage_us_note": "stages timed in stream order (events between them)" + (
+        "stage_us_note": "stages timed in stream order (events between them); us_per_pipeline from a second pass without them" + (
             "; us_per_pipeline is the pipeline as run: the mesh sweep on a side stream beside the "
             f"{'all-gather and the ' if world > 1 else ''}pairwise pass ({wall_serial_max / reps * 1e6:.1f} us in stream order)"
             if tris is not None else ""),
-        "solve_failures": cnt[0], "pairwise_hits": cnt[1], "pairwise_hits_fixture": int(fix[f"cfg{cfg}_pair_hit_idx"].size),
+        "solve_failures": cnt[0], "pairwise_hits": cnt[1],
+        "pairwise_hits_fixture": int(fix[f"cfg{cfg}_pair_hit_idx"].size) if fix is not None else None,
         "stages": {
             "solve": {"kernel": grid_kernel, "bound": "hbm",
                       "frac": algorithmic_bytes(n_max, M, order) / (st["solve"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -467,7 +516,10 @@ def run_formation_config(cfg, env, reps, warm):
                                           "time grids takes), outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "pairwise": {"kernel": "msnap::collide_span_kernel + collide_merge_kernel", "bound": "valu_f64",
+            "pairwise": {"kernel": ("msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)"
+                                    if world == 1 else "msnap::collide_transpose_kernel + collide_span_kernel + "
+                                    "collide_merge_kernel on this rank's part of the swarm's pairs"),
+                         "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": True,
                          "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "tflops": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
@@ -481,34 +533,46 @@ def run_formation_config(cfg, env, reps, warm):
         },
     }
     if world > 1:
+        coll_name = "all_gather_into_tensor (RCCL)" if env["coll"] is dist else "host rehearsal (gloo)"
+        pb = ctx.formation_part_bytes(N)
         rep["stages"]["allgather"] = {
-            "collective": "all_gather_into_tensor (RCCL)" if env["coll"] is dist else "host rehearsal (gloo)",
-            "bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24,
+            "collective": coll_name, "bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24,
             "frac": (N - n_max) * S * 24 / (st["allgather"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
+        rep["stages"]["allgather_parts"] = {
+            "collective": coll_name, "bound": "xgmi (latency)", "bytes_received_per_rank": (world - 1) * pb,
+            "what": "per-drone partial minima of every rank's part: 12 bytes per drone and rank",
+            "frac": (world - 1) * pb / (st["allgather_parts"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
+        rep["stages"]["fold"] = {"kernel": "msnap::collide_finish_kernel", "bound": "latency"}
     if cfg == 3:
         rep["mesh_hits"] = cnt[2]
-        rep["mesh_hits_fixture"] = int(fix["cfg3_mesh_hit_idx"].size)
+        rep["mesh_hits_fixture"] = int(fix["cfg3_mesh_hit_idx"].size) if fix is not None else None
         tests = n_max * S * int(tris.shape[0])
-        # how many of them the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
-        ctx.set_option("mesh_count_tests", 1)
-        comp.mesh(pos_keep, tris, synthetic.DRONE_RADIUS)
-        evaluated = ctx.get_option("mesh_count_tests")
-        ctx.set_option("mesh_count_tests", 0)
-        valu = pmc_counter("mesh_sweep_kernel", "SQ_INSTS_VALU") if world == 1 else None
+        evaluated = mesh_extra
+        valu, valu_src = pmc_counter("mesh_sweep_kernel", "SQ_INSTS_VALU") if world == 1 else (None, "one rank only")
         rep["stages"]["mesh"] = {
             "kernel": "msnap::mesh_sweep_kernel", "bound": "valu_f64",
-            "point_triangle_pairs": tests, "tests_evaluated": evaluated,
+            "point_triangle_pairs": tests, "tests_evaluated": evaluated, "cull_ratio": evaluated / tests,
             "point_triangle_pairs_per_s": tests / (st["mesh"] * 1e-6),
             "tests_evaluated_per_s": evaluated / (st["mesh"] * 1e-6),
-            "frac": (valu * 64 / (st["mesh"] * 1e-6) / VALU_F64_OPS) if valu else None,
-            "note": "exact cull: a triangle whose bounding box is farther from the wave's stretch of path than "
-                    "the best distance so far is skipped; frac = vector instructions per launch (SQ_INSTS_VALU "
-                    "of profiles/pmc_counters.json, this workload) x 64 lanes / time / fp64 issue peak"}
+            # algorithmic work: a full closest-point evaluation is MESH_TEST_OPS fp64 vector operations
+            "frac": evaluated * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
+            "frac_on_all_pairs": tests * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
+            "issue_utilisation": (valu * 64 / (st["mesh"] * 1e-6) / VALU_F64_OPS) if valu else None,
+            "issue_utilisation_source": valu_src,
+            "note": "exact cull: a triangle whose bounding box is farther from the wave's stretch of path than the best "
+                    f"distance so far is skipped (cull_ratio = evaluated / all pairs).  frac = evaluated tests x {MESH_TEST_OPS} "
+                    "fp64 vector operations (one full closest-point evaluation, Ericson 5.1.5: the dot products d1..d6, "
+                    "the three edge and the face region, the squared distance; counted in csrc/msnap_aux.hip::pt_tri_d2) "
+                    "/ time / fp64 issue peak; frac_on_all_pairs counts the culled pairs as done (it may exceed 1); "
+                    "issue_utilisation = SQ_INSTS_VALU x 64 lanes / time / peak from the committed counter pass, quoted "
+                    "only when that pass was taken from this build's kernel sources"}
     return rep
 
 
 def run_solve_config(env, N, M, order, reps, warm, label):
-    """configs[4]: N drones x M segments sharded by drone, solve only."""
+    """configs[4]: N drones x M segments sharded by drone, solve only.  The `reps` launches are captured in one
+    hipGraph like the headline's steps (a launch of tens of microseconds is otherwise timed together with the gap
+    an eager launch leaves between two kernels)."""
     torch, dist, device = env["torch"], env["dist"], env["device"]
     rank, world, use_pg, red_dev = env["rank"], env["world"], env["use_pg"], env["red_dev"]
     from drone_path_planning_python_amd import swarm
@@ -517,7 +581,7 @@ def run_solve_config(env, N, M, order, reps, warm, label):
     lo, hi = swarm.shard_bounds(N, world, rank)
     wp, t = synth(5, N, M)                        # every rank builds the same swarm and keeps its shard
     batch = DeviceBatch(torch, ctx, wp[lo:hi], t[lo:hi], M, order, device)
-    wall, dev_ms = timed_steps(torch, dist, batch, ctx, reps, warm, False, world if use_pg else 1)
+    wall, dev_ms = timed_steps(torch, dist, batch, ctx, reps, warm, env.get("use_graph", True), world if use_pg else 1)
     kernel = ctx.last_kernel()
     fails = int(batch.status.abs().sum().item())
     pick = np.r_[0:min(256, hi - lo), max(0, hi - lo - 256):hi - lo]
@@ -535,7 +599,9 @@ def run_solve_config(env, N, M, order, reps, warm, label):
         "stage_us": {"solve": kus}, "solve_failures": cnt[0], "max_norm_rel_err_vs_oracle": mx[2],
         "stages": {"solve": {"kernel": kernel, "bound": "hbm",
                              "algorithmic_bytes_per_launch": algorithmic_bytes(n_max, M, order),
-                             "traffic": pmc_traffic(n_max, M, order)[0],
+                             "traffic": pmc_traffic(n_max, M, order, kernel)[0],
+                             "traffic_source": pmc_traffic(n_max, M, order, kernel)[1],
+                             "launch": "hipGraph of the timed launches" if env.get("use_graph", True) else "eager",
                              "frac": algorithmic_bytes(n_max, M, order) / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS}},
     }
 
@@ -601,6 +667,7 @@ def main():
 
     # ---- BASELINE.json configs[2..4] on all ranks (sharded), with the RCCL all-gather timed ----
     configs = None
+    strong = None
     if not args.no_configs:
         reps = args.config_reps or max(10, min(args.steps, 50))
         ctx7 = ctx if order == 7 else Context(device_id=dev_index, order=7, max_segments=64)
@@ -608,13 +675,27 @@ def main():
         for c in (ctx7, ctx9):
             c.set_stream(torch.cuda.current_stream().cuda_stream)
         env = dict(torch=torch, dist=dist, ctx7=ctx7, ctx9=ctx9, device=device, rank=rank, world=world,
-                   use_pg=use_pg, red_dev=red_dev,
+                   use_pg=use_pg, red_dev=red_dev, use_graph=use_graph,
                    coll=dist if args.backend == "nccl" else HostGather(dist))
         # ~15 ms of the same work first: the GPU's clocks settle over tens of milliseconds of load
         c2 = run_formation_config(2, env, reps, 40)
         c3 = run_formation_config(3, env, reps, 40)
         c4 = run_solve_config(env, 65536, 10, 9, reps, 40, "configs[4]")
         configs = {"2": c2, "3": c3, "4": c4}
+        # STRONG scaling (total work fixed, sharded over the ranks): what a SCALE curve over N should be read from --
+        # `value` itself is the config the metric is quoted on (256 drones per GPU, weak scaling, no collective)
+        if not args.no_strong:
+            s7 = run_solve_config(env, 65536, 10, 7, reps, 40, "65536 x 10, order 7")
+            big = run_formation_config(2, env, max(5, reps // 5), 5, n_groups=2048)
+            if rank == 0:
+                def brief(c):
+                    return {"workload": c["workload"], "sharding": c["sharding"], "value": c["value"], "unit": c["unit"],
+                            "us_per_pipeline": c["us_per_pipeline"], "stage_us": c["stage_us"]}
+                strong = {"n_gpus": world,
+                          "note": "total work fixed and sharded by drone over the ranks; value = drones / max-over-ranks time; "
+                                  "the formation pipelines include both collectives of the pairwise pass",
+                          "solve_order9_65536x10": brief(c4), "solve_order7_65536x10": brief(s7),
+                          "formation_4096x10": brief(c2), "formation_16384x10": brief(big)}
         for c in (ctx7, ctx9):
             if c is not ctx:
                 c.use_own_stream()
@@ -652,7 +733,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": b / per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": b / per / 1e9 / HBM_PEAK_GBS, "frac_of_copy_achievable": b / per / 1e9 / HBM_COPY_GBS,
                          "kernel": sat_kernel,
-                         "traffic": pmc_traffic(nbig, M, order)[0]},
+                         "traffic": pmc_traffic(nbig, M, order, sat_kernel)[0],
+                         "traffic_source": pmc_traffic(nbig, M, order, sat_kernel)[1]},
         }
         assert sat_err <= 1e-6 and not sat_bad, f"saturated leg parity {sat_err:.3e}"
         del big
@@ -706,13 +788,14 @@ def main():
         total = args.drones * world * args.steps
         per_launch_s = dev_ms_max * 1e-3 / args.steps
         bytes_launch = algorithmic_bytes(args.drones, M, order)
-        traffic = pmc_traffic(args.drones, M, order)[0]
+        traffic, traffic_source = pmc_traffic(args.drones, M, order, kname)
         roof = {
             "bound": "hbm",
             "kernel": kname,
             "achieved": bytes_launch / per_launch_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_launch / per_launch_s / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": bytes_launch,
             "avg_launch_us": per_launch_s * 1e6,
             "note": "256 drones are 788 KB: 0.1 us of HBM time under a launch floor of ~2.5 us, so this config "
@@ -751,6 +834,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "configs": configs,
+            "strong_scaling": strong,
             "saturated": sat,
             "shared_grid": grid,
             "end_to_end": e2e,

@@ -111,3 +111,18 @@ def check(lib, ctx_handle, rc: int) -> None:
     if rc == -2 and ctx_handle:
         msg += ": " + lib.msnap_last_hip_error(ctx_handle).decode()
     raise MsnapError(rc, msg)
+
+
+def csrc_sha() -> str:
+    """sha256 (first 16 hex digits) over csrc/*.hip and csrc/*.h, in name order: the identity of the kernel
+    sources.  Committed PMC summaries carry it (tools/pmc_summary.py, tools/make_pipeline_profile.sh) and
+    bench.py only quotes counters whose value matches the sources it runs."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]

@@ -743,6 +743,9 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
     // lane first folds its own rows (the lower row wins a tie); the 64 candidates of a column go through the
     // LDS image [column][lane]; lane = kColBlock * part + column then scans its part of the column and the
     // parts are folded with cross-lane exchanges.  Rows past the batch end replay row R-1 and must not win.
+    // (The lane index is taken from an opaque copy: left visible, the fold's lane-derived addresses are hoisted
+    // out of the share's loops and kept -- in scratch -- across the column loop, whose 128 registers are spoken for.)
+    asm volatile("" : "+v"(lane));
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       double v = rs.live[0] ? acc[0][c] : INFINITY;
@@ -952,7 +955,7 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   const int r = r_raw < g.R ? r_raw : g.R - 1;
   double best = INFINITY;
   int bj = -1;
-  constexpr int U = 4;      // entries fetched per round: the loads of a round are independent
+  constexpr int U = 8;      // entries fetched per round: the loads of a round are independent
   auto sweep = [&](const double *pd, const int32_t *pj, size_t pitch, int n) {
     for (int s0 = q; s0 < n; s0 += U * kMergeParts) {
       double v[U];

@@ -14,7 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p49 -- python3 tool
 # vector-instruction counts of the two collision kernels on the same workload (bench.py's mesh roofline)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 tools/formation_pipeline.py --config 3 --reps 10 > /dev/null 2> $OUT/pmc3.err || exit 1
 python3 - "$OUT" <<'PY'
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.getcwd())
+from drone_path_planning_python_amd._lib import csrc_sha
 out = sys.argv[1]
 with open(out + "/pipeline_summary.md", "w") as f:
     for tag, title in (("c2", "configs[2]: 4096 drones x 10 segments (formation fixture), 91 samples, pairwise pass"),
@@ -37,9 +39,12 @@ with open(out + "/pipeline_summary.md", "w") as f:
                 if k in r["Kernel_Name"]:
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    counters["csrc_sha"] = csrc_sha()      # bench.py quotes these counters only for the sources they were taken from
     json.dump(counters, open(out + "/pmc_counters.json", "w"), indent=1)
     f.write("### PMC counters per launch, configs[3] workload (mean)\n\n| kernel | counter | value |\n|---|---|---|\n")
     for k, cs in sorted(counters.items()):
+        if not isinstance(cs, dict):
+            continue
         for c, v in sorted(cs.items()):
             f.write(f"| `{k}` | {c} | {v:.6g} |\n")
 PY

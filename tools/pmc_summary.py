@@ -15,6 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from drone_path_planning_python_amd._lib import csrc_sha  # noqa: E402
+
 
 def main():
     root = sys.argv[1]
@@ -50,7 +53,7 @@ def main():
         fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024.0
         write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024.0
         drones = int(wl.split("x")[0])
-        traffic[wl] = {"kernel": name, "drones": drones, "fetch_bytes_raw": fetch,
+        traffic[wl] = {"kernel": name, "drones": drones, "csrc_sha": csrc_sha(), "fetch_bytes_raw": fetch,
                        "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write,
                        "hbm_bytes_per_launch": 2 * fetch + write}
     print()
