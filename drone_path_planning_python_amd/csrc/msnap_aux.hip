@@ -551,12 +551,13 @@ struct CollideGeom {
   int upw_tail;             // units per share behind `split` (smaller shares even out the end of the launch)
   long long split;          // first unit of the tail shares (a multiple of upw)
   int sparts;               // sample parts: a share of the line is taken by `sparts` waves, each a range of chunks
-  long long total;          // units of the launch
-  // One rank's part of a pass over the whole swarm (msnap_formation_collide_part): the launch covers the shares
-  // [w_lo, w_hi) of the global line, which touch the row blocks I_lo .. I_hi; the transposed row image and the
-  // partial buffers are indexed relative to them, and the merge writes the squared minimum of EVERY drone
-  // (+inf / -1 where this part met none of its pairs) instead of distances.  Whole launches: 0, shares, 0, n_rb - 1.
-  long long w_lo, w_hi;
+  long long total;          // units of the whole line
+  // The launch walks the units [u_lo, u_lo + u_n) of the line, cut into its own shares (`split` is relative to
+  // u_lo); they touch the row blocks I_lo .. I_hi.  A whole pass: 0, total, 0, n_rb - 1.  One rank's part of a
+  // pass over the whole swarm (msnap_formation_collide_part, `part` = 1): a contiguous 1/P of the line; the
+  // transposed row image and the partial buffers are indexed relative to I_lo, and the merge writes the squared
+  // minimum of EVERY drone (+inf / -1 where this part met none of its pairs) instead of distances.
+  long long u_lo, u_n;
   int I_lo, I_hi;
   int part;
 };
@@ -571,10 +572,11 @@ __device__ __host__ __forceinline__ long long collide_ustart(const CollideGeom &
 __device__ __host__ __forceinline__ long long collide_share_begin(const CollideGeom &g, long long w) {
   const long long w1 = g.split / g.upw;                  // shares of the head
   const long long u = w <= w1 ? w * g.upw : g.split + (w - w1) * g.upw_tail;
-  return u < g.total ? u : g.total;
+  return g.u_lo + (u < g.u_n ? u : g.u_n);
 }
-__device__ __host__ __forceinline__ long long collide_share_of(const CollideGeom &g, long long u) {
-  return u < g.split ? u / g.upw : g.split / g.upw + (u - g.split) / g.upw_tail;
+__device__ __host__ __forceinline__ long long collide_share_of(const CollideGeom &g, long long u) {   // u: a unit of the launch
+  const long long ul = u - g.u_lo;
+  return ul < g.split ? ul / g.upw : g.split / g.upw + (ul - g.split) / g.upw_tail;
 }
 
 // 6 samples of a column drone = 18 contiguous doubles in scalar registers.  The loads are issued by
@@ -838,10 +840,9 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
-  const int wl = blockIdx.x / g.sparts, h = blockIdx.x - wl * g.sparts;
-  const long long w = g.w_lo + wl;
+  const int w = blockIdx.x / g.sparts, h = blockIdx.x - w * g.sparts;
   long long u = collide_share_begin(g, w);
-  const long long u_end = collide_share_begin(g, w + 1);
+  const long long u_end = collide_share_begin(g, (long long)w + 1);
   if (u >= u_end) return;
   // the row block the share starts in
   int I = 0;
@@ -888,7 +889,7 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
-    const size_t id = ((size_t)wl + (I - g.I_lo)) * g.sparts + h;
+    const size_t id = ((size_t)w + (I - g.I_lo)) * g.sparts + h;
 #pragma unroll
     for (int rr = 0; rr < kRowsPerLane; ++rr) {
       part_d2[id * kRowBlock + rr * kWave + lane] = rs.best[rr];
@@ -979,11 +980,12 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   if (g.total > 0) {
     // row side: the shares of this launch that met this drone's row block
     const int I = r / kRowBlock;
-    long long wf = collide_share_of(g, collide_ustart(g, I)), wl = collide_share_of(g, collide_ustart(g, I + 1) - 1);
-    wf = wf < g.w_lo ? g.w_lo : wf;
-    wl = wl >= g.w_hi ? g.w_hi - 1 : wl;
-    if (wl >= wf) {
-      const size_t first = ((size_t)(wf - g.w_lo) + (I - g.I_lo)) * g.sparts * kRowBlock + (r - I * kRowBlock);
+    long long ua = collide_ustart(g, I), ub = collide_ustart(g, I + 1) - 1;      // the row block's units ...
+    ua = ua < g.u_lo ? g.u_lo : ua;                                                // ... that this launch walks
+    ub = ub >= g.u_lo + g.u_n ? g.u_lo + g.u_n - 1 : ub;
+    if (ub >= ua) {
+      const long long wf = collide_share_of(g, ua), wl = collide_share_of(g, ub);
+      const size_t first = ((size_t)wf + (I - g.I_lo)) * g.sparts * kRowBlock + (r - I * kRowBlock);
       sweep(part_d2 + first, part_j + first, kRowBlock, (int)(wl - wf + 1) * g.sparts);
     }
     // column side: the row blocks of this launch before this drone's own (each left `sparts` entries per
@@ -1063,8 +1065,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   g.n_rb = (n_rows + kRowBlock - 1) / kRowBlock;
   g.Rp = g.n_rb * kRowBlock;
   g.sparts = 1;
-  g.w_lo = 0;
-  g.w_hi = 0;
+  g.u_lo = 0;
+  g.u_n = 0;
   g.I_lo = 0;
   g.I_hi = g.n_rb - 1;
   g.part = 0;
@@ -1100,6 +1102,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   ctx->collide_last_sym = g.sym;
   g.upw = 1;
   g.total = collide_ustart(g, g.n_rb);
+  g.u_n = g.total;
   // Equal contiguous shares of the line, one 8-column block (x 128 rows) each.  Many small shares beat one
   // share per resident wave: the dispatcher hands the next share to whichever SIMD frees a slot, which
   // evens out the speed differences between SIMDs; shares of 4 columns everywhere lose more to the
@@ -1135,7 +1138,6 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.split = (shares - shares % slots) * upw;
   }
   waves = g.split / upw + (g.total - g.split + g.upw_tail - 1) / g.upw_tail;
-  g.w_hi = waves;
   // A small launch (a small swarm, or one of many shards) is as long as ONE share takes -- 16 sample chunks x 8
   // columns are one dependent chain of scalar fetches, 43 us at 512 drones whatever the arithmetic.  While the
   // shares do not fill a quarter of the wave slots (half-full launches lose: 512 of 4096 rows 71 -> 84 us), each
@@ -1202,34 +1204,51 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   g.os = 0;
   g.oe = N;
   g.sym = 1;
-  g.upw = g.upw_tail = kColBlock;
   g.total = collide_ustart(g, g.n_rb);
-  const long long shares = (g.total + kColBlock - 1) / kColBlock;
-  g.split = shares * kColBlock;
-  g.w_lo = shares * part / n_parts;
-  g.w_hi = shares * (part + 1) / n_parts;
+  // part p walks the units [total * p / P, total * (p + 1) / P) of the line, the cuts rounded to whole 8-column blocks
+  auto cut = [&](int p) {
+    const long long u = g.total * p / n_parts / kColBlock * kColBlock;
+    return p >= n_parts ? g.total : u;
+  };
+  g.u_lo = cut(part);
+  g.u_n = cut(part + 1) - g.u_lo;
   g.part = 1;
   g.sparts = 1;
+  g.upw = g.upw_tail = kColBlock;
   g.I_lo = 0;
   g.I_hi = -1;
-  const long long waves = g.w_hi - g.w_lo;
-  if (waves > 0) {
-    const long long u0 = collide_share_begin(g, g.w_lo), u1 = collide_share_begin(g, g.w_hi) - 1;
+  const long long shares = (g.u_n + kColBlock - 1) / kColBlock;
+  g.split = shares * kColBlock;
+  long long waves = shares;
+  if (shares > 0) {
+    const long long u0 = g.u_lo, u1 = g.u_lo + g.u_n - 1;
     while (g.I_lo + 1 < g.n_rb && collide_ustart(g, g.I_lo + 1) <= u0) ++g.I_lo;
     g.I_hi = g.I_lo;
     while (g.I_hi + 1 < g.n_rb && collide_ustart(g, g.I_hi + 1) <= u1) ++g.I_hi;
-    // A part that does not fill half of the wave slots is as long as one share's chain of fetches (16 chunks
-    // x 8 columns): its shares are split by sample range.  Measured at 4096 x 91 (rocprofv3, span kernel alone /
-    // merge): an eighth of the line, 1056 shares: 54 / 8 us whole, 43 / 11 us in halves, 40 / 17 us in
-    // quarters, 46 / 31 us in eighths -- every split multiplies the partial entries the merge sweeps; a quarter
-    // of the line, 2112 shares: 72 us whole or in halves.
+    // Filling the wave slots (4 per SIMD) ONCE is what a part launch is tuned for -- nothing refills a slot that
+    // frees early, and a launch that exceeds the slots by a few shares runs those as a round of their own
+    // (4096 x 91 in two parts: 4224 shares on 4096 slots took 133 us against 112 for half of the single launch).
+    //  * fewer shares than slots: every share is taken by floor(slots / shares) waves, each a range of the sample
+    //    chunks (a share alone is one chain of 16 x 8 dependent fetches; an eighth of the 4096-drone line,
+    //    1056 shares, span kernel alone / merge under rocprofv3: 54 / 8 us whole, 43 / 11 in halves, 40 / 17 in
+    //    quarters -- 4224 waves, 128 of them queued -- 46 / 31 in eighths; every split multiplies the partial
+    //    entries the merge sweeps)
+    //  * a few shares more than whole rounds of the slots: the excess goes out as 2-column shares (the whole-pass
+    //    rule above)
     const long long slots = (long long)ctx->n_cu * 4 * 4;
+    const int nch = (n_samples + kSampleChunk - 1) / kSampleChunk;
     if (ctx->collide_sample_parts > 0) {
       g.sparts = ctx->collide_sample_parts < 8 ? ctx->collide_sample_parts : 8;
-    } else {
-      const int nch = (n_samples + kSampleChunk - 1) / kSampleChunk;
-      while (g.sparts < 8 && waves * g.sparts < slots / 2 && nch / (g.sparts * 2) >= 2) g.sparts *= 2;
+    } else if (shares * 2 <= slots) {
+      long long sp = slots / shares;
+      sp = sp > 8 ? 8 : sp;
+      while (sp > 1 && nch / sp < 2) --sp;
+      g.sparts = (int)sp;
+    } else if (shares % slots != 0 && shares % slots <= slots / 8 && shares > slots) {
+      g.upw_tail = 2;
+      g.split = (shares - shares % slots) * kColBlock;
     }
+    waves = g.split / kColBlock + (g.u_n - g.split + g.upw_tail - 1) / g.upw_tail;
   }
   const int nrb = g.I_hi - g.I_lo + 1;                 // row blocks this part touches (0: an empty part)
   g.Rp = (nrb > 0 ? nrb : 1) * kRowBlock;
