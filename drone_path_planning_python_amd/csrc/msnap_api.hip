@@ -20,6 +20,11 @@ int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what) {
 
 int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return MSNAP_OK;
+  // growing synchronises the stream and frees the old block: neither is legal while the stream is being
+  // captured into a graph, and a capture must not silently record a launch on a buffer that is about to go
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (ctx->stream && hipStreamIsCapturing(ctx->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
+    return MSNAP_ECAPTURE;
   if (b.p) {
     MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MSNAP_HIP(ctx, hipFree(b.p));
@@ -91,6 +96,7 @@ const char *msnap_strerror(int code) {
     case MSNAP_ENOMEM: return "out of memory";
     case MSNAP_ENODEVICE: return "no usable gfx950 device";
     case MSNAP_ENOGRID: return "no time grid prepared on this context (msnap_grid_prepare)";
+    case MSNAP_ECAPTURE: return "a scratch buffer would have to grow during stream capture: run the call once outside the capture first";
     default: return "unknown msnap error";
   }
 }

@@ -47,7 +47,10 @@ enum msnap_error {
   MSNAP_ESEGMENTS = -4,   /* n_seg < 1 or n_seg > max_segments of the context */
   MSNAP_ENOMEM = -5,      /* host or device allocation failed                 */
   MSNAP_ENODEVICE = -6,   /* no gfx950 device / device_id out of range        */
-  MSNAP_ENOGRID = -7      /* msnap_solve_grid without a prepared grid          */
+  MSNAP_ENOGRID = -7,     /* msnap_solve_grid without a prepared grid          */
+  MSNAP_ECAPTURE = -8     /* a scratch buffer of the context would have to grow while its stream is being
+                             captured into a graph (growing synchronises and frees): run the same call once
+                             outside the capture first -- the buffers then have their size */
 };
 
 enum msnap_status {       /* per-drone, written to status[]                   */

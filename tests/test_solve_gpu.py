@@ -871,3 +871,44 @@ def test_hip_path_reproduces_the_reference_output_files(ctx7, fname):
     matrix, _, _ = gen.paths_to_pols([path], ctx7)
     assert "grid_gemm_stream_kernel" in ctx7.last_kernel()
     check(matrix[0], "paths_to_pols")
+
+
+def test_buffer_growth_inside_a_stream_capture_is_refused():
+    """A context's scratch buffers grow by synchronising and freeing -- illegal while the stream is being captured
+    into a graph.  A first-time-larger call inside a capture must come back with MSNAP_ECAPTURE instead of
+    recording a launch on a buffer that is about to go; after one call outside the capture the same capture works
+    and its replay gives the eager result."""
+    import torch
+    from drone_path_planning_python_amd import Context, MsnapError
+    from drone_path_planning_python_amd.synthetic import swarm
+    n, m = 48, 49                                   # 49 segments: the stash lives on the context's global slab
+    wp, t = swarm(4242, n, m)
+    dev = torch.device("cuda", 0)
+    twp, tt = torch.from_numpy(wp).to(dev), torch.from_numpy(t).to(dev)
+    coef = torch.zeros((n, m, 4, 8), dtype=torch.float64, device=dev)
+    dur = torch.zeros((n, m), dtype=torch.float64, device=dev)
+    st = torch.zeros((n,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    with Context(order=7, max_segments=64) as ctx:
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with pytest.raises(MsnapError) as e:
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                    ctx.solve_batch_device(n, m, twp, tt, False, coef, dur, st)
+            assert e.value.code == -8
+            ctx.set_stream(side.cuda_stream)
+            ctx.solve_batch_device(n, m, twp, tt, False, coef, dur, st)      # sizes the slab
+            assert "solve_kernel<4, true>" in ctx.last_kernel()
+            side.synchronize()
+            eager = coef.clone()
+            coef.zero_()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                ctx.solve_batch_device(n, m, twp, tt, False, coef, dur, st)
+            ctx.set_stream(side.cuda_stream)
+            g2.replay()
+            side.synchronize()
+            assert torch.equal(coef, eager) and int(st.abs().sum().item()) == 0
+        ctx.use_own_stream()
