@@ -1662,7 +1662,12 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   const int ntiles = (N + kDronesPerWave - 1) / kDronesPerWave;
   const size_t tr_bytes = (size_t)K * kTrPitch * 16;   // output transpose image, NC/2 = K rows
   // up to one 8-drone wavefront per SIMD the two-sided kernel wins (measured crossover 8-10 k drones on 256 CUs)
-  const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones : ctx->n_cu * 4 * kTwistDrones;
+  // (order 9 with an even segment count <= 10: the two-sided column-split throughput kernel already wins from one
+  // 8-drone wave per CU on -- 4096 x 10: 9.2 against 11.2 us, 8192 x 10: 11.0 against 16.3 -- the straight-line
+  // latency kernel below that: 1024 x 10: 7.1 against 7.4 us; tools/order9_sizes.py)
+  const bool twin_ok = (K == 5 && M >= 4 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_twin9);
+  const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
+                                                  : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {
     // small batch: at most one wavefront per SIMD -- halve the dependent chain instead
     const int nt8 = (N + kTwistDrones - 1) / kTwistDrones;
@@ -1697,7 +1702,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
-  if (K == 5 && M >= 4 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_twin9) {
+  if (twin_ok) {
     // order 9, large batch, even segment count: two-sided column-split kernel at two waves per SIMD
     const int nt8 = (N + kTwinDrones - 1) / kTwinDrones;
     int grid = ctx->n_cu * 8 * 8;
