@@ -22,15 +22,19 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   configs      every BASELINE.json config on this many GPUs, each with per-stage microseconds
                (HIP events on the launching stream, median over the repetitions, max over ranks), roofline fraction and bound:
                  [1] 256 x 10 (the headline again)
-                 [2] 4096 x 10: solve -> sample -> all-gather -> pairwise formation pass
+                 [2] 4096 x 10: solve -> sample -> pairwise formation pass
                  [3] 4096 x 20: the same + sweep against resources/stl/env-scene-hole.stl and
                      env-scene-ltu-experiment.stl
-                 [4] 65536 x 10, order 9
-               For N > 1 configs [2]-[4] are SHARDED by drone over the ranks (strong scaling)
-               and the RCCL all_gather_into_tensor of the sampled positions is inside the timed
-               region.  [2]/[3] run on the formation-like inputs pinned by
-               tests/golden/formation_golden.npz and report their hit counts beside the
-               fixture's.
+                 [4] 65536 x 10, order 9 (its launches under a hipGraph, like the headline's)
+               For N > 1 configs [2]-[4] are SHARDED by drone over the ranks (strong scaling): the
+               formation pass becomes sample -> RCCL all-gather of the positions -> this rank's PART of
+               the swarm's unordered pairs (every pair on exactly one rank) -> all-gather of the
+               12-byte-per-drone partial minima -> fold, both collectives inside the timed region.
+               [2]/[3] run on the formation-like inputs pinned by tests/golden/formation_golden.npz
+               and report their hit counts beside the fixture's.
+  strong_scaling  total work fixed and sharded over the ranks (what a SCALE curve over N should be read
+               from; `value` is the 256-drone-per-GPU config of the metric and scales trivially):
+               configs[4], 65536 x 10 at order 7, the 4096-drone and a 16384-drone formation pipeline
   saturated    the solve kernel on a batch large enough to fill the chip (2^20 drones), with its
                own roofline fraction and the parity of its first and last 4096 drones against
                the C oracle -- the 256-drone headline is launch/latency-bound by construction
