@@ -982,7 +982,15 @@ __device__ __forceinline__ double quad_bcast(double v) {   // lane SRC of the qu
 }
 
 constexpr int kTwinSlotWords = 16 * 16;          // one knot's G: 16 entries x 16 (drone, side) blocks
-constexpr int kTwinTrWords = 5 * kTrPitch * 2;   // output transposition image (NC/2 = 5 rows)
+// Output transposition image of the twin kernel: 5 rows (coefficient pairs) of kTwinTrPitch 16-byte slots.  A lane
+// writes piece p at slot p * pitch + lane (8 contiguous lanes per LDS cycle: conflict-free for any pitch) and reads
+// back, with store q, piece (a2, j2) = ((4q + j) / 5, (4q + j) % 5) of its own block at slot j2 * pitch + 4 * blk + a2.
+// ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, ... (blocks 0, 3, 5, 6: all residues mod 4) and a slot
+// covers 4 of the 64 banks, so the 16 slots of a group must differ mod 16: with pitch = 1 (mod 16) they are
+// a2 + j2 + 4 * blk, distinct for every q (pitch 68 = 4 (mod 16), the one-sided kernels' choice for their flat
+// read-back order, made 4 of them collide here: SQ_LDS_BANK_CONFLICT 2.0 of 9.9 M LDS cycles per launch).
+constexpr int kTwinTrPitch = 65;
+constexpr int kTwinTrWords = 5 * kTwinTrPitch * 2;   // in doubles
 constexpr int kTwinDrones = 8;
 
 // Output stores of the twin kernel.  The 4 axis lanes of a (drone, side) block hold the block's 320 bytes as
@@ -1001,7 +1009,7 @@ __device__ __forceinline__ void twin_store_plan(int lane, TwinStorePlan &pl) {
     const int within = q * 4 + j;            // 16-byte piece of the block: (axis a2, pair j2)
     const int a2 = within / 5;
     const int j2 = within - a2 * 5;
-    pl.ridx[q] = j2 * kTrPitch + blk4 + a2;
+    pl.ridx[q] = j2 * kTwinTrPitch + blk4 + a2;
   }
 }
 
@@ -1010,7 +1018,7 @@ __device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__res
                                                      const TwinStorePlan &pl, const double (&c)[10]) {
   constexpr int NJ = 5;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) sTr[j * kTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
+  for (int j = 0; j < NJ; ++j) sTr[j * kTwinTrPitch + lane] = make_double2(c[2 * j], c[2 * j + 1]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
