@@ -981,7 +981,6 @@ __device__ __forceinline__ double quad_bcast(double v) {   // lane SRC of the qu
   return __hiloint2double(hi, lo);
 }
 
-constexpr int kTwinSlotWords = 16 * 16;          // one knot's G: 16 entries x 16 (drone, side) blocks
 // Output transposition image of the twin kernel: 5 rows (coefficient pairs) of kTwinTrPitch 16-byte slots.  A lane
 // writes piece p at slot p * pitch + lane (8 contiguous lanes per LDS cycle: conflict-free for any pitch) and reads
 // back, with store q, piece (a2, j2) = ((4q + j) / 5, (4q + j) % 5) of its own block at slot j2 * pitch + 4 * blk + a2.
@@ -1028,13 +1027,16 @@ __device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__res
   __builtin_amdgcn_wave_barrier();
 }
 
-inline size_t twin9_lds_bytes(int n_seg) {
+inline size_t twin_lds_bytes(int khalf, int n_seg) {
   const size_t h = (size_t)(n_seg - 2) / 2;
-  const size_t g_words = h * kTwinSlotWords;                  // h knots x 16 entries x 16 (drone, side) blocks
+  const size_t g_words = h * (size_t)(khalf - 1) * kWave;     // h knots x NU rows x 16 (drone, side) blocks x 4 column slots
   const size_t in_words = (size_t)kTwinDrones * (n_seg + 1) * 5;
-  const size_t body = (size_t)kTwinTrWords + g_words;
+  const size_t body = (khalf == 5 ? (size_t)kTwinTrWords : 0) + g_words;
   return (in_words > body ? in_words : body) * sizeof(double);
 }
+// waves per SIMD an instance is built for (registers: 512 / waves per lane)
+template <int K, int M>
+constexpr int kTwinWaves = 2;
 
 // cross-tile input prefetch of the twin kernel: the hand-issued loads and exact wait of solve_kernel_reg
 // (stage_load_asm / stage_wait_asm), for 8 drones per tile and a compile-time segment count
@@ -1096,17 +1098,27 @@ __device__ __forceinline__ void twin_stage_store(int shared_times, int nvalid, d
   }
 }
 
-template <int M>
-__global__ void __launch_bounds__(kWave, 2)
-solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
-                   int N, double *__restrict__ coef, double *__restrict__ dur,
-                   int32_t *__restrict__ status, int ntiles) {
-  constexpr int K = 5;
+// gather the symmetric Schur block from the lanes' columns: entry (n, m), m <= n, is element n of lane m's column
+template <int NU, int NS, int MCOL = 0>
+__device__ __forceinline__ void twin_gather(const double (&col)[NU], double (&OtG)[NS]) {
+  if constexpr (MCOL < NU) {
+#pragma unroll
+    for (int n = MCOL; n < NU; ++n) OtG[sidx(n, MCOL)] = quad_bcast<MCOL>(col[n]);
+    twin_gather<NU, NS, MCOL + 1>(col, OtG);
+  }
+}
+
+template <int K, int M>
+__global__ void __launch_bounds__(kWave, (kTwinWaves<K, M>))
+solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, int shared_times,
+                  int N, double *__restrict__ coef, double *__restrict__ dur,
+                  int32_t *__restrict__ status, int ntiles) {
   using SW = Sweep<K>;
   using C = HermiteConsts<K>;
   constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
-  static_assert(NU == kAxes, "one column of the knot blocks per axis lane");
+  static_assert(NU <= kAxes && NU >= 3, "one column of the knot blocks per axis lane (order 7: the fourth lane idles through the column work)");
   static_assert(M >= 4 && (M % 2) == 0, "both sides own (M-2)/2 >= 1 knots");
+  constexpr int kSlotWords = NU * kWave;      // one knot's G: [row][16 (drone, side) blocks][4 column slots]
   constexpr int H = (M - 2) / 2;              // knots per side; the meeting knot is knot H+1 of both
   constexpr int HA = H > 0 ? H : 1;
 
@@ -1115,11 +1127,12 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
   const int lane0 = threadIdx.x;
   constexpr int wpitch = (M + 1) * 4;
   constexpr int tpitch = M + 1;
-  // LDS: [ transposition image | G: [knot][row][16 blocks][column] ]; the input stage aliases both (dead before the first use)
+  // LDS: [ transposition image (order 9 only) | G: [knot][row][16 blocks][column] ]; the input stage aliases both
+  // (dead before the first use)
   double *sWraw = lds;
   double *sTraw = sWraw + kTwinDrones * wpitch;
   double2 *sTr = reinterpret_cast<double2 *>(lds);
-  double *sG = lds + kTwinTrWords;
+  double *sG = lds + (NC == 10 ? kTwinTrWords : 0);
   double dsg[NU];
 #pragma unroll
   for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
@@ -1132,7 +1145,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
   // segments of the backward sweep and retired at the tile top by an exact vmcnt that leaves those two
   // segments' 2 x kStoresPerSeg stores in flight (every instance has H >= 1, so both always run)
   static_assert(H >= 1, "the prefetch sits in front of segments 1 and 0 of the backward sweep");
-  constexpr int kStoresPerSeg = NC / 2;
+  constexpr int kStoresPerSeg = (NC == 8 ? 4 : NC / 2);
   TwinStage<M> pre;
   if ((int)blockIdx.x < ntiles)
     twin_stage_load<M>(wp, tt, shared_times, blockIdx.x, tile_valid(blockIdx.x), lane0, pre);
@@ -1151,7 +1164,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     double ca[NU];
 #pragma unroll
     for (int n = 0; n < NU; ++n)
-      ca[n] = a == 0 ? C::HSE[n + 1][1] : a == 1 ? C::HSE[n + 1][2] : a == 2 ? C::HSE[n + 1][3] : C::HSE[n + 1][4];
+      ca[n] = a == 0 ? C::HSE[n + 1][1] : a == 1 ? C::HSE[n + 1][2] : a == 2 ? C::HSE[n + 1][3] : C::HSE[n + 1][NU];
     const int d_raw = tile * kTwinDrones + dl;
     const bool live = d_raw < N;
     const int d = live ? d_raw : N - 1;
@@ -1236,7 +1249,9 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       }
       double dinv[NU];
       singular |= SW::ldl_factor(S, dinv);
-      const double pa = a == 0 ? xp[4] : a == 1 ? xp[3] : a == 2 ? xp[2] : xp[1];
+      // (order 7: lane 3 has no column; it runs the same instructions on column 3's constants and lands in the
+      //  unused fourth column slot of the stash)
+      const double pa = a == 0 ? xp[NU] : a == 1 ? xp[NU - 1] : a == 2 ? xp[NU - 2] : xp[NU - 3];
       double g[NU];
 #pragma unroll
       for (int n = 0; n < NU; ++n) g[n] = ca[n] * (n == NU - 1 ? pa : pa * xp[NU - 1 - n]);
@@ -1244,7 +1259,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       SW::ldl_solve(S, dinv, y);
       {
         // [knot][row r][block][column a]: the 64 lanes of a store write 64 consecutive doubles
-        double *gs = sG + (it - 1) * kTwinSlotWords + lane;
+        double *gs = sG + (it - 1) * kSlotWords + lane;
 #pragma unroll
         for (int r = 0; r < NU; ++r) gs[r * kWave] = g[r];
       }
@@ -1267,13 +1282,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
         col[n] = sg * xp[NU - n];
         rz[n] = __builtin_fma(sz, xp[NU - n], rz[n]);
       }
-#pragma unroll
-      for (int n = 0; n < NU; ++n) {
-        OtG[sidx(n, 0)] = quad_bcast<0>(col[n]);
-        if (n >= 1) OtG[sidx(n, 1)] = quad_bcast<1>(col[n]);
-        if (n >= 2) OtG[sidx(n, 2)] = quad_bcast<2>(col[n]);
-        if (n >= 3) OtG[sidx(n, 3)] = quad_bcast<3>(col[n]);
-      }
+      twin_gather<NU, NS>(col, OtG);
 #pragma unroll
       for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
     }
@@ -1309,8 +1318,8 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     const double zero_or_nan = bad ? qnan : 0.0;
     // drones past the batch end replay the tile's last valid one (bitwise the same values) and store on top of it
     TwinStorePlan plan;
-    twin_store_plan(lane, plan);
-    double *blkp = coef + ((size_t)d * M + (side ? M - 1 - H : H)) * (4 * NC) + a * 2;
+    if constexpr (NC == 10) twin_store_plan(lane, plan);
+    double *blkp = coef + ((size_t)d * M + (side ? M - 1 - H : H)) * (4 * NC) + (NC == 10 ? a * 2 : 0);
     const int blkstep = side ? 4 * NC : -(4 * NC);   // side 0 walks its segments down, side 1 up
 #pragma unroll
     for (int i = 0; i < H + 2; ++i) wreg[i] = bad ? qnan : wreg[i];
@@ -1319,6 +1328,9 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
     for (int r = 0; r < NU; ++r) un[r] = bad ? qnan : um[r];
 #pragma unroll
     for (int it = H; it >= 0; --it) {
+      // one segment at a time: left free, the scheduler issues the G reads of ALL knots at the top of the sweep and
+      // holds them (12 registers per knot: 85 / 128 / 166 / 202 / 242 registers at 4..12 segments, order 7)
+      if (it != 1) __builtin_amdgcn_sched_barrier(0);
       if (it == 1) {
         // with two segments left most of this tile's registers are dead: the next tile's inputs start now
         // (unconditional, clamped to the last tile, at a static point of the unrolled loop)
@@ -1328,7 +1340,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       }
       double u[NU];
       if (it >= 1) {
-        const double2 *gsl = reinterpret_cast<const double2 *>(sG + (it - 1) * kTwinSlotWords + blk * NU);
+        const double2 *gsl = reinterpret_cast<const double2 *>(sG + (it - 1) * kSlotWords + blk * kAxes);
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
           const double2 g01 = gsl[r * (kWave / 2)], g23 = gsl[r * (kWave / 2) + 1];
@@ -1336,7 +1348,7 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
           v = __builtin_fma(-g01.x, un[0], v);
           v = __builtin_fma(-g01.y, un[1], v);
           v = __builtin_fma(-g23.x, un[2], v);
-          v = __builtin_fma(-g23.y, un[3], v);
+          if constexpr (NU == 4) v = __builtin_fma(-g23.y, un[3], v);
           u[r] = v;
         }
       } else {
@@ -1354,7 +1366,8 @@ solve_kernel_twin9(const double *__restrict__ wp, const double *__restrict__ tt,
       double c[NC];
       recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
       if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-      store_twin_coalesced(sTr, blkp, lane, plan, c);
+      if constexpr (NC == 10) store_twin_coalesced(sTr, blkp, lane, plan, c);
+      else store_quad8_at(blkp, a, c, false);      // order 7: the quad transposes its 4 x 4 pieces with DPP, no LDS
       blkp += blkstep;
 #pragma unroll
       for (int r = 0; r < NU; ++r) un[r] = u[r];
@@ -1660,7 +1673,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
-constexpr int kTwinMaxSeg = 10;   // order 9, even n_seg <= 10, large batches: solve_kernel_twin9
+constexpr int kTwinMaxSeg = 10;    // order 9, even n_seg <= 10, batches beyond one wave per CU: solve_kernel_twin
+constexpr int kTwinMaxSeg7 = 12;   // order 7, even n_seg <= 12 (14 segments and more spill at 256 registers as written)
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
@@ -1673,7 +1687,11 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   // (order 9 with an even segment count <= 10: the two-sided column-split throughput kernel already wins from one
   // 8-drone wave per CU on -- 4096 x 10: 9.2 against 11.2 us, 8192 x 10: 11.0 against 16.3 -- the straight-line
   // latency kernel below that: 1024 x 10: 7.1 against 7.4 us; tools/order9_sizes.py)
-  const bool twin_ok = (K == 5 && M >= 4 && M <= kTwinMaxSeg && (M % 2) == 0 && !ctx->no_twin9);
+  // (order 7, tools/order9_sizes.py with PROBE_ORDER=7, 10 segments: 4096 drones 7.4 us against 8.6 (small-batch
+  //  kernel) and 11.0 (solve_kernel_reg); 8192: 8.9 / 12.8 / 12.9; 16 384: 13.4 / - / 16.2; 32 768: 21.6 / - / 22.1;
+  //  65 536: 41.5 / - / 40.4 -- from 128 drones per CU on the 16-drone waves of solve_kernel_reg are ahead again)
+  const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && (M % 2) == 0 && !ctx->no_twin &&
+                        (K == 5 || N <= ctx->n_cu * 128));
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
                                                   : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {
@@ -1711,20 +1729,27 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     return MSNAP_OK;
   }
   if (twin_ok) {
-    // order 9, large batch, even segment count: two-sided column-split kernel at two waves per SIMD
+    // large batch, even segment count: two-sided column-split kernel
     const int nt8 = (N + kTwinDrones - 1) / kTwinDrones;
     int grid = ctx->n_cu * 8 * 8;
     if (ctx->solve_grid_waves > 0) grid = ctx->solve_grid_waves;
     if (grid > nt8) grid = nt8;
-#define MSNAP_TWIN(MM)                                                                                          \
-  case MM:                                                                                                      \
-    note_kernel(ctx, "msnap::solve_kernel_twin9<%d>", MM);                                                      \
-    hipLaunchKernelGGL((solve_kernel_twin9<MM>), dim3(grid), dim3(kWave), twin9_lds_bytes(MM), ctx->stream, wp, \
-                       t, shared, N, coef, dur, status, nt8);                                                   \
+#define MSNAP_TWIN(MM)                                                                                            \
+  case MM:                                                                                                        \
+    note_kernel(ctx, "msnap::solve_kernel_twin<%d, %d>", K, MM);                                                  \
+    hipLaunchKernelGGL((solve_kernel_twin<K, MM>), dim3(grid), dim3(kWave), twin_lds_bytes(K, MM), ctx->stream,   \
+                       wp, t, shared, N, coef, dur, status, nt8);                                                 \
     break;
-    switch (M) {
-      MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
-      default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+    if constexpr (K == 5) {
+      switch (M) {
+        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
+        default: return MSNAP_EINVAL;   // unreachable: the range is checked above
+      }
+    } else {
+      switch (M) {
+        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12)
+        default: return MSNAP_EINVAL;
+      }
     }
 #undef MSNAP_TWIN
     MSNAP_HIP(ctx, hipGetLastError());

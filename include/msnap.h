@@ -63,7 +63,7 @@ enum msnap_status {       /* per-drone, written to status[]                   */
 int msnap_version(void);                       /* 10000*major + 100*minor + patch */
 const char *msnap_strerror(int code);
 const char *msnap_last_hip_error(const msnap_ctx *ctx);
-/* Name (as a profiler prints it, e.g. "msnap::solve_kernel_twin9<10>") of the kernel instance the most recent
+/* Name (as a profiler prints it, e.g. "msnap::solve_kernel_twin<5, 10>") of the kernel instance the most recent
  * solve entry point of this context launched -- msnap_solve_batch[_device] or msnap_solve_grid[_device];
  * "" before the first one.  The choice depends on order, segment count, batch size and the options above. */
 const char *msnap_last_kernel(const msnap_ctx *ctx);
@@ -91,7 +91,7 @@ int msnap_host_free(void *ptr);
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
- *   "no_twin9"             1: order-9 batches stay on the one-sided throughput kernel where the two-sided
+ *   "no_twin"             1: order-9 batches stay on the one-sided throughput kernel where the two-sided
  *                          column-split one would run (A/B timing)
  *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 8-column x 128-row block per share)
  *   "collide_sample_parts" waves per share of the pairwise pass, each a range of the sample chunks
@@ -109,7 +109,7 @@ int msnap_host_free(void *ptr);
  *                          runs on a lowest-priority stream: its workgroups are dispatched when the
  *                          other queue has none waiting
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
- * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN9, MSNAP_COLLIDE_WAVES_PER_CU and
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_COLLIDE_WAVES_PER_CU and
  * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
 int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value);

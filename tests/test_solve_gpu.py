@@ -191,7 +191,7 @@ def test_order9_against_extended_precision(gold9, name):
         coef, _, status = ctx.solve_batch(wp, t)
         assert (status == 0).all()
         errs[ctx.last_kernel()] = norm_rel(coef, ref)
-        ctx.set_option("no_twin9", 1)
+        ctx.set_option("no_twin", 1)
         coef, _, status = ctx.solve_batch(wp, t)
         assert (status == 0).all()
         errs[ctx.last_kernel()] = norm_rel(coef, ref)
@@ -203,7 +203,7 @@ def test_order9_against_extended_precision(gold9, name):
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs and max(errs.values()) <= TIGHT9, errs
     if M in (4, 6, 8, 10):
-        assert any("twin9" in k for k in errs), errs
+        assert any("solve_kernel_twin<5" in k for k in errs), errs
 
 
 @pytest.mark.parametrize("m", [1, 2, 7, 10, 12, 16])
@@ -598,12 +598,15 @@ def _solve_in_shards(ctx, wp, t, shard):
 
 
 @pytest.mark.parametrize("shared", [False, True])
-@pytest.mark.parametrize("order,m,waves", [(7, 10, 5), (7, 7, 3), (7, 20, 5), (7, 14, 4), (9, 10, 5), (9, 16, 3),
-                                           (9, 20, 4)])
-def test_persistent_solve_walks_several_tiles(order, m, waves, shared):
-    """solve_kernel_reg<4|5, 10|20> with a grid of `waves` wavefronts: 600-odd drones are 38 tiles,
-    so every wave walks 7-13 tiles and the last tile is partial.  The result must equal, bit for
-    bit, the same batch solved 16 drones (one tile, no prefetch) at a time, and match the C oracle."""
+@pytest.mark.parametrize("order,m,waves,twin", [(7, 10, 5, False), (7, 7, 3, False), (7, 20, 5, False), (7, 14, 4, False),
+                                                (9, 10, 5, False), (9, 16, 3, False), (9, 20, 4, False),
+                                                (7, 10, 5, True), (7, 4, 3, True), (7, 12, 7, True), (9, 10, 5, True),
+                                                (9, 6, 4, True)])
+def test_persistent_solve_walks_several_tiles(order, m, waves, shared, twin):
+    """The persistent throughput kernels with a grid of `waves` wavefronts -- solve_kernel_reg<4|5, 10|20> (16 drones
+    per tile: 600-odd drones are 38 tiles) and the two-sided solve_kernel_twin<4|5, M> (8 per tile: 76 tiles) -- so
+    every wave walks 7-25 tiles and the last tile is partial.  The result must equal, bit for
+    bit, the same batch solved 16 drones (one or two tiles, no prefetch wait) at a time, and match the C oracle."""
     from drone_path_planning_python_amd import Context
     from drone_path_planning_python_amd.synthetic import swarm
     n = 16 * 37 + 9
@@ -611,8 +614,10 @@ def test_persistent_solve_walks_several_tiles(order, m, waves, shared):
     if not shared:
         t[3] += 0.2                                      # one drone with the t[0] != 0 quirk
     with Context(order=order, max_segments=64) as ctx:
-        ctx.set_option("no_twist", 1)                   # keep every launch on solve_kernel_reg
+        ctx.set_option("no_twist", 1)                   # keep every launch on the throughput kernels
+        ctx.set_option("no_twin", 0 if twin else 1)
         one_tile = _solve_in_shards(ctx, wp, t, 16)      # grid = 1 wave, one tile: the prefetch never waits
+        assert ("solve_kernel_twin" in ctx.last_kernel()) == twin, ctx.last_kernel()
         ctx.set_option("solve_grid_waves", waves)
         assert ctx.get_option("solve_grid_waves") == waves
         multi = ctx.solve_batch(wp, t)
@@ -631,18 +636,21 @@ def test_persistent_solve_walks_several_tiles(order, m, waves, shared):
     np.testing.assert_array_equal(bad[0][keep], multi[0][keep])
 
 
-@pytest.mark.parametrize("name", ["cfg2", "m20"])
-def test_persistent_solve_goldens_multi_tile(golden, name):
+@pytest.mark.parametrize("name,twin", [("cfg2", False), ("m20", False), ("cfg2", True)])
+def test_persistent_solve_goldens_multi_tile(golden, name, twin):
     """The reference's own outputs (cfg2: 64 x 10, m20: 8 x 20, tiled to several tiles per wave)
-    through solve_kernel_reg with two persistent waves."""
+    through the throughput kernels with two persistent waves: solve_kernel_reg, and for cfg2 also the
+    two-sided solve_kernel_twin<4, 10>."""
     from drone_path_planning_python_amd import Context
     wp, t, ref = golden[name + "_wp"], golden[name + "_t"], golden[name + "_coef"]
     reps = 200 // wp.shape[0] + 1
     wpx, tx, refx = np.tile(wp, (reps, 1, 1)), np.tile(t, (reps, 1)), np.tile(ref, (reps, 1, 1, 1))
     with Context(order=7, max_segments=64) as ctx:
         ctx.set_option("no_twist", 1)
+        ctx.set_option("no_twin", 0 if twin else 1)
         ctx.set_option("solve_grid_waves", 2)
         coef, dur, status = ctx.solve_batch(wpx, tx)
+        assert ("solve_kernel_twin" in ctx.last_kernel()) == twin
     assert (status == 0).all()
     assert norm_rel(coef, refx) <= TIGHT
     np.testing.assert_array_equal(dur, np.tile(golden[name + "_dur"], (reps, 1)))
@@ -804,20 +812,27 @@ def test_last_kernel_reports_the_launched_instance():
         ctx.set_option("no_twist", 1)
         wp, t = swarm(78, 300, 10)
         ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_twin<4, 10>"      # even segment counts <= 12: two-sided kernel
+        ctx.set_option("no_twin", 1)
+        ctx.solve_batch(wp, t)
         assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 10>"
+        ctx.set_option("no_twin", 0)
+        wp, t = swarm(78, 300, 7)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 10>"       # odd: the one-sided register kernel
         wp, t = swarm(79, 40, 10, shared_times=True)
         ctx.prepare_grid(t)
         ctx.solve_grid(wp)
         assert ctx.last_kernel() == "msnap::grid_gemm_kernel<8, 10>"
     with Context(order=9, max_segments=64) as ctx:
         ctx.set_option("no_twist", 1)
-        for m, want in [(10, "msnap::solve_kernel_twin9<10>"), (6, "msnap::solve_kernel_twin9<6>"),
+        for m, want in [(10, "msnap::solve_kernel_twin<5, 10>"), (6, "msnap::solve_kernel_twin<5, 6>"),
                         (7, "msnap::solve_kernel_reg<5, 10>"), (2, "msnap::solve_kernel_reg<5, 10>"),
                         (16, "msnap::solve_kernel_reg<5, 20>")]:
             wp, t = swarm(80 + m, 100, m)
             ctx.solve_batch(wp, t)
             assert ctx.last_kernel() == want
-        ctx.set_option("no_twin9", 1)
+        ctx.set_option("no_twin", 1)
         wp, t = swarm(90, 100, 10)
         ctx.solve_batch(wp, t)
         assert ctx.last_kernel() == "msnap::solve_kernel_reg<5, 10>"

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Build-time check of the hand-counted cross-tile prefetch of solve_kernel_reg and solve_kernel_twin9
+"""Build-time check of the hand-counted cross-tile prefetch of solve_kernel_reg and solve_kernel_twin
 (csrc/msnap_solve.hip).
 
 The persistent solve issues the next tile's input loads from inline asm during the last two
 segments of a tile and retires them with `s_waitcnt vmcnt(N)`, N <= the store instructions issued
 after them (the compiler does not see asm loads, so nothing else would wait for them, and a wait
 that is too loose would read registers whose loads have not landed).  This script disassembles the
-gfx950 code object inside msnap_solve.o and checks, for every solve_kernel_reg / solve_kernel_twin9 instance:
+gfx950 code object inside msnap_solve.o and checks, for every solve_kernel_reg / solve_kernel_twin instance:
   1. the in-loop prefetch burst exists (UW dwordx4 + UT dwordx2 loads back to back);
   2. the kernel holds exactly MAXM x kStoresPerSeg coefficient stores (global_store_dwordx4: 4 per
      segment at order 7, 5 at order 9): the compiler neither merged, split nor dropped one;
@@ -54,8 +54,8 @@ def kernel_shape(name):
     m = re.search(r"solve_kernel_regILi(\d+)ELi(\d+)E", name)
     if m:
         return int(m.group(1)), int(m.group(2))          # K = 4 (order 7) or 5 (order 9), MAXM segments
-    m = re.search(r"solve_kernel_twin9ILi(\d+)E", name)
-    return 5, int(m.group(1)) // 2                        # order 9, every side stores its M/2 segments
+    m = re.search(r"solve_kernel_twinILi(\d+)ELi(\d+)E", name)
+    return int(m.group(1)), int(m.group(2)) // 2          # K, and every side stores its M/2 segments
 
 
 def check_kernel(name, body):
@@ -175,7 +175,7 @@ def main():
     text = disassemble(obj)
     kernels, cur = {}, None
     for ln in text.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(_ZN5msnap(?:16solve_kernel_reg|18solve_kernel_twin9)\w+)>:", ln)
+        m = re.match(r"^[0-9a-f]+ <(_ZN5msnap(?:16solve_kernel_reg|17solve_kernel_twin)\w+)>:", ln)
         if m:
             cur = m.group(1)
             kernels[cur] = []
@@ -190,8 +190,8 @@ def main():
             t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", ln)
             base = kernels[cur][0][1] if kernels[cur] else int(m.group(1), 16)
             kernels[cur].append((text, int(m.group(1), 16), base + int(t.group(1), 16) if t else None))
-    if len(kernels) != 8:
-        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 4 solve_kernel_twin9 instances, found {len(kernels)}")
+    if len(kernels) != 13:
+        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 9 solve_kernel_twin instances, found {len(kernels)}")
         return 1
     res = {n: check_kernel(n, b) for n, b in sorted(kernels.items())}
     bad = [e for e in res.values() if e]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Order-9 large-batch solve, A/B over the kernel choice ("no_twin9": 0 two-sided column-split kernel,
+"""Order-9 large-batch solve, A/B over the kernel choice ("no_twin": 0 two-sided column-split kernel,
 1 solve_kernel_reg<5,10>) and the persistent grid.
    python tools/order9_ab.py [drones=65536] [segments=10]"""
 import os
@@ -30,7 +30,7 @@ ctx.set_option("no_twist", 1)
 bytes_ = N * (8 * 5 * (M + 1) + 8 * M * (1 + 4 * (order + 1)))
 ref = None
 for mode in (0, 1, 0):
-    ctx.set_option("no_twin9", mode)
+    ctx.set_option("no_twin", mode)
     for waves in (0, 2048, 4096):
         ctx.set_option("solve_grid_waves", waves)
         for _ in range(40):
@@ -47,6 +47,6 @@ for mode in (0, 1, 0):
         if ref is None:
             ref = c.copy()
         err = float((np.abs(c - ref).max(axis=(1, 3)) / np.abs(ref).max(axis=(1, 3))).max())
-        print(f"no_twin9={mode} {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak; "
+        print(f"no_twin={mode} {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak; "
               f"vs solve_kernel_reg {err:.2e}; status ok {bool((st == 0).all())}", flush=True)
 ctx.close()

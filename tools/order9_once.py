@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few launches of the order-9 large-batch solve for profilers.
-   python tools/order9_once.py [drones=65536] [segments=10] [no_twin9=0] [launches=20]"""
+   python tools/order9_once.py [drones=65536] [segments=10] [no_twin=0] [launches=20]"""
 import os
 import sys
 
@@ -28,7 +28,7 @@ st = torch.empty((N,), dtype=torch.int32, device=dev)
 ctx = Context(0, order, 64)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ctx.set_option("no_twist", 1)
-ctx.set_option("no_twin9", mode)
+ctx.set_option("no_twin", mode)
 for _ in range(launches):
     ctx.solve_batch_device(N, M, twp, tt, False, coef, dur, st)
 torch.cuda.synchronize()

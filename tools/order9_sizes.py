@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Order-9 solve over batch sizes (configs[4] sharded over 1..8 GPUs is 65536..8192 drones per rank): the launcher's
-choice against the alternatives ("no_twist" keeps small batches off the two-sided latency kernel, "no_twin9" keeps
+choice against the alternatives ("no_twist" keeps small batches off the two-sided latency kernel, "no_twin" keeps
 large ones on solve_kernel_reg).   python tools/order9_sizes.py [segments=10] [N ...]"""
 import os
 import sys
@@ -15,7 +15,7 @@ from drone_path_planning_python_amd.synthetic import swarm  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 sizes = [int(x) for x in sys.argv[2:]] or [2048, 4096, 8192, 16384, 32768, 65536]
-order = 9
+order = int(os.environ.get("PROBE_ORDER", "9"))
 dev = torch.device("cuda", 0)
 for N in sizes:
     wp, t = swarm(5, N, M)
@@ -24,7 +24,7 @@ for N in sizes:
     dur = torch.empty((N, M), dtype=torch.float64, device=dev)
     st = torch.empty((N,), dtype=torch.int32, device=dev)
     bytes_ = N * (8 * 5 * (M + 1) + 8 * M * (1 + 4 * (order + 1)))
-    for opts in ({}, {"no_twist": 1}, {"no_twist": 1, "no_twin9": 1}):
+    for opts in ({}, {"no_twist": 1}, {"no_twist": 1, "no_twin": 1}):
         ctx = Context(0, order, 64)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         for k, v in opts.items():
@@ -46,7 +46,7 @@ for N in sizes:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
-        print(f"order 9 {N:6d} x {M}: {ctx.last_kernel():40s} {us:7.2f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak "
+        print(f"order {order} {N:6d} x {M}: {ctx.last_kernel():40s} {us:7.2f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak "
               f"({N / us:.1f} traj/us)", flush=True)
         ctx.use_own_stream()
         ctx.close()
