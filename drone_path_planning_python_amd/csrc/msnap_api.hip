@@ -54,7 +54,7 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
 };
 
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
@@ -70,6 +70,7 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "twist_max_drones")) return &ctx->twist_max_drones;
   if (!strcmp(name, "no_twist")) return &ctx->no_twist;
   if (!strcmp(name, "no_twin")) return &ctx->no_twin;
+  if (!strcmp(name, "twin_max_drones")) return &ctx->twin_max_drones;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;
   if (!strcmp(name, "collide_no_sym")) return &ctx->collide_no_sym;

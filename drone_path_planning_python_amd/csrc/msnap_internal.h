@@ -74,6 +74,7 @@ struct msnap_ctx {
   // seed them in msnap_create -- nothing on a launch path reads the environment)
   int no_twist = 0;             // "no_twist": keep small batches on the one-sided kernels (A/B timing)
   int no_twin = 0;             // "no_twin": batches keep solve_kernel_reg where solve_kernel_twin would run (A/B timing)
+  int twin_max_drones = 0;      // "twin_max_drones": largest batch that takes solve_kernel_twin (0: default per order)
   int twist_max_drones = 0;     // "twist_max_drones": batches up to this size take the small-batch kernel (0: default)
   int solve_grid_waves = 0;     // "solve_grid_waves": cap on solve_kernel_reg's persistent grid (0: default)
   int gemm_grid_waves = 0;      // "gemm_grid_waves": cap on the shared-grid GEMM's persistent grid (0: default)

@@ -882,6 +882,14 @@ solve_kernel_reg(const double *__restrict__ wp, const double *__restrict__ tt, i
         xreg[i] = rcp64(Ti);
         double G[NU][NU], z[NU];
         sw.step(xreg[i], wreg[i + 1] - wreg[i], G, z);
+        {   // the checks of this knot settled here, in one register: left as booleans the compares are sunk behind the
+            // sweep and every |w|, T and pivot waits for them in registers (see solve_kernel_twin)
+          int f = (nonfinite ? 4 : 0) | (badtime ? 2 : 0) | (sw.singular ? 1 : 0);
+          asm volatile("" : "+v"(f));
+          nonfinite = (f & 4) != 0;
+          badtime = (f & 2) != 0;
+          sw.singular = (f & 1) != 0;
+        }
         if (i < M - 1) {
           double *g = sG + (i - 1) * (NU * NU * 16) + dl;
 #pragma unroll
@@ -1035,8 +1043,10 @@ inline size_t twin_lds_bytes(int khalf, int n_seg) {
   return (in_words > body ? in_words : body) * sizeof(double);
 }
 // waves per SIMD an instance is built for (registers: 512 / waves per lane)
+// (registers as built: order 7: 81 / 96 / 124 / 148 / 175 at 4 / 6 / 8 / 10 / 12 segments; order 9: 92 / 123 / 164 / 201
+//  at 4 / 6 / 8 / 10)
 template <int K, int M>
-constexpr int kTwinWaves = 2;
+constexpr int kTwinWaves = (K == 4 ? (M <= 10 ? 3 : 2) : (M <= 8 ? 3 : 2));
 
 // cross-tile input prefetch of the twin kernel: the hand-issued loads and exact wait of solve_kernel_reg
 // (stage_load_asm / stage_wait_asm), for 8 drones per tile and a compile-time segment count
@@ -1209,6 +1219,10 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
       }
       xreg[i] = rcp64(T);
     }
+    // The input checks are settled HERE, in one register: left as booleans the compares are sunk to where the status
+    // is formed -- behind both sweeps -- and every |w|, |T| and T waits there in registers (32 of them at 10 segments).
+    int in_flags = (nonfinite ? 4 : 0) | (badtime ? 2 : 0);
+    asm volatile("" : "+v"(in_flags));
     wave_lds_fence();   // the input stage is dead: the image and the G slots alias it
 
     // ---- forward sweep over this side's knots (column split) ----
@@ -1227,7 +1241,6 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
 #pragma unroll
       for (int e = 0; e < NS; ++e) OtG[e] = 0.0;
     }
-    bool singular = false;
 #pragma unroll
     for (int it = 1; it <= H; ++it) {
       double xp[PM + 1];
@@ -1248,7 +1261,8 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
         rz[n - 1] = C::HEE[n][0] * tdw;
       }
       double dinv[NU];
-      singular |= SW::ldl_factor(S, dinv);
+      in_flags |= SW::ldl_factor(S, dinv) ? 1 : 0;
+      asm volatile("" : "+v"(in_flags));      // (the pivot checks settled per knot, for the same reason)
       // (order 7: lane 3 has no column; it runs the same instructions on column 3's constants and lands in the
       //  unused fourth column slot of the stash)
       const double pa = a == 0 ? xp[NU] : a == 1 ? xp[NU - 1] : a == 2 ? xp[NU - 2] : xp[NU - 3];
@@ -1301,14 +1315,14 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
     }
     {
       double dinv[NU];
-      singular |= SW::ldl_factor(Sm, dinv);
+      in_flags |= SW::ldl_factor(Sm, dinv) ? 1 : 0;
       SW::ldl_solve(Sm, dinv, um);
     }
 
     const int gsh = lane & ~7;
-    const bool f_nonfinite = ((__ballot(nonfinite) >> gsh) & 0xFFull) != 0;
-    const bool f_time = ((__ballot(badtime) >> gsh) & 0xFFull) != 0;
-    const bool f_sing = ((__ballot(singular) >> gsh) & 0xFFull) != 0;
+    const bool f_nonfinite = ((__ballot((in_flags & 4) != 0) >> gsh) & 0xFFull) != 0;
+    const bool f_time = ((__ballot((in_flags & 2) != 0) >> gsh) & 0xFFull) != 0;
+    const bool f_sing = ((__ballot((in_flags & 1) != 0) >> gsh) & 0xFFull) != 0;
     const int st = f_nonfinite ? MSNAP_ST_NONFINITE : f_time ? MSNAP_ST_TIMES : f_sing ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
     if (live && (lane & 7) == 0) status[d] = st;
     const bool bad = st != 0;
@@ -1363,8 +1377,13 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
       }
       const double wa = side ? wreg[it + 1] : wreg[it];
       const double wb = side ? wreg[it] : wreg[it + 1];
+      // 1/T through an opaque copy: left visible, the powers of 1/T the recovery needs are recognised as the forward
+      // sweep's and kept from there to here -- 6-8 registers per knot and side (85 / 128 / 166 / 202 / 242 registers at
+      // 4..12 segments, order 7, before; three or four multiplies per segment instead)
+      double xi = xreg[it];
+      asm volatile("" : "+v"(xi));
       double c[NC];
-      recover_segment<K>(wa, wb - wa, xreg[it], ua, ub, c);
+      recover_segment<K>(wa, wb - wa, xi, ua, ub, c);
       if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
       if constexpr (NC == 10) store_twin_coalesced(sTr, blkp, lane, plan, c);
       else store_quad8_at(blkp, a, c, false);      // order 7: the quad transposes its 4 x 4 pieces with DPP, no LDS
@@ -1689,9 +1708,10 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   // latency kernel below that: 1024 x 10: 7.1 against 7.4 us; tools/order9_sizes.py)
   // (order 7, tools/order9_sizes.py with PROBE_ORDER=7, 10 segments: 4096 drones 7.4 us against 8.6 (small-batch
   //  kernel) and 11.0 (solve_kernel_reg); 8192: 8.9 / 12.8 / 12.9; 16 384: 13.4 / - / 16.2; 32 768: 21.6 / - / 22.1;
-  //  65 536: 41.5 / - / 40.4 -- from 128 drones per CU on the 16-drone waves of solve_kernel_reg are ahead again)
+  //  65 536: 42.0 / - / 43.4 (eager launches); 2^20: 0.70 ms against 0.634 -- beyond 256 drones per CU the 16-drone
+  //  waves of solve_kernel_reg are ahead)
   const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && (M % 2) == 0 && !ctx->no_twin &&
-                        (K == 5 || N <= ctx->n_cu * 128));
+                        (ctx->twin_max_drones > 0 ? N <= ctx->twin_max_drones : (K == 5 || N <= ctx->n_cu * 256)));
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
                                                   : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {

@@ -91,6 +91,8 @@ int msnap_host_free(void *ptr);
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
+ *   "twin_max_drones"      largest batch that takes the two-sided column-split throughput kernel (0 = default:
+ *                          order 7 up to 128 drones per CU, order 9 any size)
  *   "no_twin"             1: order-9 batches stay on the one-sided throughput kernel where the two-sided
  *                          column-split one would run (A/B timing)
  *   "collide_waves_per_cu" shares per CU of the pairwise pass (0 = one 8-column x 128-row block per share)
@@ -109,7 +111,7 @@ int msnap_host_free(void *ptr);
  *                          runs on a lowest-priority stream: its workgroups are dispatched when the
  *                          other queue has none waiting
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
- * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_COLLIDE_WAVES_PER_CU and
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU and
  * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
 int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value);
