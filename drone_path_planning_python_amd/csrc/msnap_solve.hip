@@ -1043,8 +1043,8 @@ inline size_t twin_lds_bytes(int khalf, int n_seg) {
   return (in_words > body ? in_words : body) * sizeof(double);
 }
 // waves per SIMD an instance is built for (registers: 512 / waves per lane)
-// (registers as built: order 7: 81 / 96 / 124 / 148 / 175 at 4 / 6 / 8 / 10 / 12 segments; order 9: 92 / 123 / 164 / 201
-//  at 4 / 6 / 8 / 10)
+// (registers as built: order 7: 81 / 96 / 124 / 148 / 175 / 202 / 233 / 256 at 4 / 6 / ... / 18 segments; order 9:
+//  92 / 123 / 164 / 201 / 242 at 4 / 6 / 8 / 10 / 12)
 template <int K, int M>
 constexpr int kTwinWaves = (K == 4 ? (M <= 10 ? 3 : 2) : (M <= 8 ? 3 : 2));
 
@@ -1692,8 +1692,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
-constexpr int kTwinMaxSeg = 10;    // order 9, even n_seg <= 10, batches beyond one wave per CU: solve_kernel_twin
-constexpr int kTwinMaxSeg7 = 12;   // order 7, even n_seg <= 12 (14 segments and more spill at 256 registers as written)
+constexpr int kTwinMaxSeg = 12;    // order 9, even n_seg <= 12, batches beyond one wave per CU: solve_kernel_twin (14: 40 B of scratch)
+constexpr int kTwinMaxSeg7 = 18;   // order 7, even n_seg <= 18 (20: 32 B of scratch at 256 registers)
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
@@ -1762,12 +1762,13 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     break;
     if constexpr (K == 5) {
       switch (M) {
-        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10)
+        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12)
         default: return MSNAP_EINVAL;   // unreachable: the range is checked above
       }
     } else {
       switch (M) {
-        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12)
+        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12) MSNAP_TWIN(14) MSNAP_TWIN(16)
+        MSNAP_TWIN(18)
         default: return MSNAP_EINVAL;
       }
     }

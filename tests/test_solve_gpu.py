@@ -202,7 +202,7 @@ def test_order9_against_extended_precision(gold9, name):
             errs[ctx.last_kernel()] = norm_rel(coef, ref)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs and max(errs.values()) <= TIGHT9, errs
-    if M in (4, 6, 8, 10):
+    if M in (4, 6, 8, 10, 12):
         assert any("solve_kernel_twin<5" in k for k in errs), errs
 
 
@@ -600,8 +600,8 @@ def _solve_in_shards(ctx, wp, t, shard):
 @pytest.mark.parametrize("shared", [False, True])
 @pytest.mark.parametrize("order,m,waves,twin", [(7, 10, 5, False), (7, 7, 3, False), (7, 20, 5, False), (7, 14, 4, False),
                                                 (9, 10, 5, False), (9, 16, 3, False), (9, 20, 4, False),
-                                                (7, 10, 5, True), (7, 4, 3, True), (7, 12, 7, True), (9, 10, 5, True),
-                                                (9, 6, 4, True)])
+                                                (7, 10, 5, True), (7, 4, 3, True), (7, 12, 7, True), (7, 18, 6, True),
+                                                (9, 10, 5, True), (9, 6, 4, True), (9, 12, 5, True)])
 def test_persistent_solve_walks_several_tiles(order, m, waves, shared, twin):
     """The persistent throughput kernels with a grid of `waves` wavefronts -- solve_kernel_reg<4|5, 10|20> (16 drones
     per tile: 600-odd drones are 38 tiles) and the two-sided solve_kernel_twin<4|5, M> (8 per tile: 76 tiles) -- so
