@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__res
 }
 
 inline size_t twin_lds_bytes(int khalf, int n_seg) {
-  const size_t h = (size_t)(n_seg - 2) / 2;
+  const size_t h = (size_t)(n_seg - 2) - (size_t)(n_seg - 2) / 2;     // knots of the longer side
   const size_t g_words = h * (size_t)(khalf - 1) * kWave;     // h knots x NU rows x 16 (drone, side) blocks x 4 column slots
   const size_t in_words = (size_t)kTwinDrones * (n_seg + 1) * 5;
   const size_t body = (khalf == 5 ? (size_t)kTwinTrWords : 0) + g_words;
@@ -1046,7 +1046,7 @@ inline size_t twin_lds_bytes(int khalf, int n_seg) {
 // (registers as built: order 7: 81 / 96 / 124 / 148 / 175 / 202 / 233 / 256 at 4 / 6 / ... / 18 segments; order 9:
 //  92 / 123 / 164 / 201 / 242 at 4 / 6 / 8 / 10 / 12)
 template <int K, int M>
-constexpr int kTwinWaves = (K == 4 ? (M <= 10 ? 3 : 2) : (M <= 8 ? 3 : 2));
+constexpr int kTwinWaves = 2;
 
 // cross-tile input prefetch of the twin kernel: the hand-issued loads and exact wait of solve_kernel_reg
 // (stage_load_asm / stage_wait_asm), for 8 drones per tile and a compile-time segment count
@@ -1127,9 +1127,15 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
   using C = HermiteConsts<K>;
   constexpr int NU = SW::NU, NC = SW::NC, NS = SW::NS, KK = SW::KK, PM = SW::PM;
   static_assert(NU <= kAxes && NU >= 3, "one column of the knot blocks per axis lane (order 7: the fourth lane idles through the column work)");
-  static_assert(M >= 4 && (M % 2) == 0, "both sides own (M-2)/2 >= 1 knots");
+  static_assert(M >= 4, "both sides own at least one knot");
   constexpr int kSlotWords = NU * kWave;      // one knot's G: [row][16 (drone, side) blocks][4 column slots]
-  constexpr int H = (M - 2) / 2;              // knots per side; the meeting knot is knot H+1 of both
+  // M - 1 interior knots = nL (side 0) + the meeting knot + nR (side 1), nL <= nR <= nL + 1.  With an odd segment
+  // count side 1 owns one knot and one segment more: all lanes run H = nR knot steps -- side 0's last one works on
+  // valid data of the other side's territory and its effect on the carried state is undone (solve_kernel_twist) --
+  // and side 0 sits out the first segment of the backward sweep.
+  constexpr int nL = (M - 2) / 2, nR = (M - 2) - nL;
+  constexpr int H = nR;
+  constexpr bool kAsym = nL != nR;
   constexpr int HA = H > 0 ? H : 1;
 
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1154,7 +1160,7 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
   // cross-tile prefetch as in solve_kernel_reg: the next tile's inputs are requested before the last two
   // segments of the backward sweep and retired at the tile top by an exact vmcnt that leaves those two
   // segments' 2 x kStoresPerSeg stores in flight (every instance has H >= 1, so both always run)
-  static_assert(H >= 1, "the prefetch sits in front of segments 1 and 0 of the backward sweep");
+  static_assert(nL >= 1, "the prefetch sits in front of segments 1 and 0 of the backward sweep, which both sides own");
   constexpr int kStoresPerSeg = (NC == 8 ? 4 : NC / 2);
   TwinStage<M> pre;
   if ((int)blockIdx.x < ntiles)
@@ -1243,6 +1249,15 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
     }
 #pragma unroll
     for (int it = 1; it <= H; ++it) {
+      double xpp0[PM], rz0[NU], OtG0[NS];     // side 0's carried state in front of its phantom step
+      if (kAsym && it == H) {
+#pragma unroll
+        for (int p = 0; p < PM; ++p) xpp0[p] = xpp[p];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) rz0[r] = rz[r];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) OtG0[e] = OtG[e];
+      }
       double xp[PM + 1];
       SW::powers(xreg[it], xp);
       const double dw = wreg[it + 1] - wreg[it];
@@ -1261,7 +1276,7 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
         rz[n - 1] = C::HEE[n][0] * tdw;
       }
       double dinv[NU];
-      in_flags |= SW::ldl_factor(S, dinv) ? 1 : 0;
+      in_flags |= (SW::ldl_factor(S, dinv) && (!kAsym || it <= nL || side)) ? 1 : 0;   // (not side 0's phantom step)
       asm volatile("" : "+v"(in_flags));      // (the pivot checks settled per knot, for the same reason)
       // (order 7: lane 3 has no column; it runs the same instructions on column 3's constants and lands in the
       //  unused fourth column slot of the stash)
@@ -1299,6 +1314,14 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
       twin_gather<NU, NS>(col, OtG);
 #pragma unroll
       for (int p = 1; p <= PM; ++p) xpp[p - 1] = xp[p];
+      if (kAsym && it == H) {       // side 0 keeps what it carried in front of the phantom step
+#pragma unroll
+        for (int p = 0; p < PM; ++p) xpp[p] = side ? xpp[p] : xpp0[p];
+#pragma unroll
+        for (int r = 0; r < NU; ++r) rz[r] = side ? rz[r] : rz0[r];
+#pragma unroll
+        for (int e = 0; e < NS; ++e) OtG[e] = side ? OtG[e] : OtG0[e];
+      }
     }
 
     // ---- the meeting knot (solve_kernel_twist): S = (E - O^T G)_own + D (E - O^T G)_other D ----
@@ -1352,6 +1375,7 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
         const int nx = next < ntiles ? next : ntiles - 1;
         twin_stage_load<M>(wp, tt, shared_times, nx, tile_valid(nx), lane, pre);
       }
+      const bool own = !kAsym || it <= nL || side != 0;     // side 0 sits out segment nR of an odd path
       double u[NU];
       if (it >= 1) {
         const double2 *gsl = reinterpret_cast<const double2 *>(sG + (it - 1) * kSlotWords + blk * kAxes);
@@ -1385,11 +1409,13 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
       double c[NC];
       recover_segment<K>(wa, wb - wa, xi, ua, ub, c);
       if (side == 0 && it == 0 && t0 != 0.0) taylor_shift<NC>(c, -t0);
-      if constexpr (NC == 10) store_twin_coalesced(sTr, blkp, lane, plan, c);
-      else store_quad8_at(blkp, a, c, false);      // order 7: the quad transposes its 4 x 4 pieces with DPP, no LDS
+      if (own) {      // (quads are side-uniform: whole quads store or sit out)
+        if constexpr (NC == 10) store_twin_coalesced(sTr, blkp, lane, plan, c);
+        else store_quad8_at(blkp, a, c, false);      // order 7: the quad transposes its 4 x 4 pieces with DPP, no LDS
+      }
       blkp += blkstep;
 #pragma unroll
-      for (int r = 0; r < NU; ++r) un[r] = u[r];
+      for (int r = 0; r < NU; ++r) un[r] = own ? u[r] : un[r];
     }
   }
 }
@@ -1710,7 +1736,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   //  kernel) and 11.0 (solve_kernel_reg); 8192: 8.9 / 12.8 / 12.9; 16 384: 13.4 / - / 16.2; 32 768: 21.6 / - / 22.1;
   //  65 536: 42.0 / - / 43.4 (eager launches); 2^20: 0.70 ms against 0.634 -- beyond 256 drones per CU the 16-drone
   //  waves of solve_kernel_reg are ahead)
-  const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && (M % 2) == 0 && !ctx->no_twin &&
+  const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && !ctx->no_twin &&
                         (ctx->twin_max_drones > 0 ? N <= ctx->twin_max_drones : (K == 5 || N <= ctx->n_cu * 256)));
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
                                                   : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
@@ -1762,12 +1788,14 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     break;
     if constexpr (K == 5) {
       switch (M) {
-        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12)
+        MSNAP_TWIN(4) MSNAP_TWIN(5) MSNAP_TWIN(6) MSNAP_TWIN(7) MSNAP_TWIN(8) MSNAP_TWIN(9) MSNAP_TWIN(10)
+        MSNAP_TWIN(11) MSNAP_TWIN(12)
         default: return MSNAP_EINVAL;   // unreachable: the range is checked above
       }
     } else {
       switch (M) {
-        MSNAP_TWIN(4) MSNAP_TWIN(6) MSNAP_TWIN(8) MSNAP_TWIN(10) MSNAP_TWIN(12) MSNAP_TWIN(14) MSNAP_TWIN(16)
+        MSNAP_TWIN(4) MSNAP_TWIN(5) MSNAP_TWIN(6) MSNAP_TWIN(7) MSNAP_TWIN(8) MSNAP_TWIN(9) MSNAP_TWIN(10)
+        MSNAP_TWIN(11) MSNAP_TWIN(12) MSNAP_TWIN(13) MSNAP_TWIN(14) MSNAP_TWIN(15) MSNAP_TWIN(16) MSNAP_TWIN(17)
         MSNAP_TWIN(18)
         default: return MSNAP_EINVAL;
       }

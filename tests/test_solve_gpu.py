@@ -202,7 +202,7 @@ def test_order9_against_extended_precision(gold9, name):
             errs[ctx.last_kernel()] = norm_rel(coef, ref)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs and max(errs.values()) <= TIGHT9, errs
-    if M in (4, 6, 8, 10, 12):
+    if 4 <= M <= 12:
         assert any("solve_kernel_twin<5" in k for k in errs), errs
 
 
@@ -601,7 +601,9 @@ def _solve_in_shards(ctx, wp, t, shard):
 @pytest.mark.parametrize("order,m,waves,twin", [(7, 10, 5, False), (7, 7, 3, False), (7, 20, 5, False), (7, 14, 4, False),
                                                 (9, 10, 5, False), (9, 16, 3, False), (9, 20, 4, False),
                                                 (7, 10, 5, True), (7, 4, 3, True), (7, 12, 7, True), (7, 18, 6, True),
-                                                (9, 10, 5, True), (9, 6, 4, True), (9, 12, 5, True)])
+                                                (9, 10, 5, True), (9, 6, 4, True), (9, 12, 5, True),
+                                                (7, 5, 3, True), (7, 7, 4, True), (7, 13, 5, True), (7, 17, 6, True),
+                                                (9, 5, 3, True), (9, 9, 5, True), (9, 11, 4, True)])
 def test_persistent_solve_walks_several_tiles(order, m, waves, shared, twin):
     """The persistent throughput kernels with a grid of `waves` wavefronts -- solve_kernel_reg<4|5, 10|20> (16 drones
     per tile: 600-odd drones are 38 tiles) and the two-sided solve_kernel_twin<4|5, M> (8 per tile: 76 tiles) -- so
@@ -819,7 +821,10 @@ def test_last_kernel_reports_the_launched_instance():
         ctx.set_option("no_twin", 0)
         wp, t = swarm(78, 300, 7)
         ctx.solve_batch(wp, t)
-        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 10>"       # odd: the one-sided register kernel
+        assert ctx.last_kernel() == "msnap::solve_kernel_twin<4, 7>"       # odd: side 1 owns a knot more
+        wp, t = swarm(78, 300, 20)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 20>"       # beyond 18 segments: the one-sided register kernel
         wp, t = swarm(79, 40, 10, shared_times=True)
         ctx.prepare_grid(t)
         ctx.solve_grid(wp)
@@ -827,7 +832,7 @@ def test_last_kernel_reports_the_launched_instance():
     with Context(order=9, max_segments=64) as ctx:
         ctx.set_option("no_twist", 1)
         for m, want in [(10, "msnap::solve_kernel_twin<5, 10>"), (6, "msnap::solve_kernel_twin<5, 6>"),
-                        (7, "msnap::solve_kernel_reg<5, 10>"), (2, "msnap::solve_kernel_reg<5, 10>"),
+                        (7, "msnap::solve_kernel_twin<5, 7>"), (2, "msnap::solve_kernel_reg<5, 10>"),
                         (16, "msnap::solve_kernel_reg<5, 20>")]:
             wp, t = swarm(80 + m, 100, m)
             ctx.solve_batch(wp, t)

@@ -55,7 +55,7 @@ def kernel_shape(name):
     if m:
         return int(m.group(1)), int(m.group(2))          # K = 4 (order 7) or 5 (order 9), MAXM segments
     m = re.search(r"solve_kernel_twinILi(\d+)ELi(\d+)E", name)
-    return int(m.group(1)), int(m.group(2)) // 2          # K, and every side stores its M/2 segments
+    return int(m.group(1)), (int(m.group(2)) + 1) // 2    # K, and the longer side's segments (one store sequence each)
 
 
 def check_kernel(name, body):
@@ -190,8 +190,8 @@ def main():
             t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", ln)
             base = kernels[cur][0][1] if kernels[cur] else int(m.group(1), 16)
             kernels[cur].append((text, int(m.group(1), 16), base + int(t.group(1), 16) if t else None))
-    if len(kernels) != 17:
-        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 13 solve_kernel_twin instances, found {len(kernels)}")
+    if len(kernels) != 28:
+        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 24 solve_kernel_twin instances, found {len(kernels)}")
         return 1
     res = {n: check_kernel(n, b) for n, b in sorted(kernels.items())}
     bad = [e for e in res.values() if e]
