@@ -1731,8 +1731,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   // up to one 8-drone wavefront per SIMD the two-sided kernel wins (measured crossover 8-10 k drones on 256 CUs)
   // (order 9 with an even segment count <= 10: the two-sided column-split throughput kernel already wins from one
   // 8-drone wave per CU on -- 4096 x 10: 9.2 against 11.2 us, 8192 x 10: 11.0 against 16.3 -- the straight-line
-  // latency kernel below that: 1024 x 10: 7.1 against 7.4 us; tools/order9_sizes.py)
-  // (order 7, tools/order9_sizes.py with PROBE_ORDER=7, 10 segments: 4096 drones 7.4 us against 8.6 (small-batch
+  // latency kernel below that: 1024 x 10: 7.1 against 7.4 us; tools/order_sizes.py)
+  // (order 7, tools/order_sizes.py with PROBE_ORDER=7, 10 segments: 4096 drones 7.4 us against 8.6 (small-batch
   //  kernel) and 11.0 (solve_kernel_reg); 8192: 8.9 / 12.8 / 12.9; 16 384: 13.4 / - / 16.2; 32 768: 21.6 / - / 22.1;
   //  65 536: 42.0 / - / 43.4 (eager launches); 2^20: 0.70 ms against 0.634 -- beyond 256 drones per CU the 16-drone
   //  waves of solve_kernel_reg are ahead)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Order-9 solve over batch sizes (configs[4] sharded over 1..8 GPUs is 65536..8192 drones per rank): the launcher's
-choice against the alternatives ("no_twist" keeps small batches off the two-sided latency kernel, "no_twin" keeps
-large ones on solve_kernel_reg).   python tools/order9_sizes.py [segments=10] [N ...]"""
+"""The solve over batch sizes (configs[4] sharded over 1..8 GPUs is 65536..8192 drones per rank), order 9 or -- with
+PROBE_ORDER=7 -- order 7: the launcher's choice against the alternatives ("no_twist" keeps small batches off the
+two-sided latency kernel, "no_twin" keeps larger ones on solve_kernel_reg), each under a hipGraph of 50 launches.
+   [PROBE_ORDER=7] python tools/order_sizes.py [segments=10] [N ...]"""
 import os
 import sys
 
