@@ -471,6 +471,7 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     torch.cuda.synchronize()
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
     k1_kernel = ctx.last_kernel()
+    pair_once = bool(ctx.get_option("collide_last_sym")) if world == 1 else True   # (parts: by construction)
     mesh_extra = None
     if cfg == 3:
         # how many point-triangle tests the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
@@ -523,7 +524,7 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
             "pairwise": {"kernel": ("msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)"
                                     if world == 1 else "msnap::collide_transpose_kernel + collide_span_kernel + "
                                     "collide_merge_kernel on this rank's part of the swarm's pairs"),
-                         "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": True,
+                         "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": pair_once,
                          "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "tflops": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,

@@ -109,7 +109,9 @@ int msnap_host_free(void *ptr);
  *                          the context's own stream (after draining it).  A pass that should only fill the
  *                          gaps of another context's work -- the mesh sweep beside the pairwise pass --
  *                          runs on a lowest-priority stream: its workgroups are dispatched when the
- *                          other queue has none waiting
+ *                          other queue has none waiting.  Setting it destroys and re-creates the stream:
+ *                          set it BEFORE msnap_get_stream() hands the handle to anybody (a wrapper around
+ *                          the old handle -- e.g. torch.cuda.ExternalStream -- would dangle)
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
  * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU and
  * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */

@@ -44,6 +44,20 @@ def test_bench_line_contract():
     assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-6
     assert set(cfg["3"]["stage_us"]) == {"solve", "sample", "pairwise", "mesh"}
     assert 0.0 < cfg["2"]["stages"]["pairwise"]["frac"] < 1.0
+    assert cfg["2"]["stages"]["pairwise"]["pairs_evaluated_once_over_all_ranks"] is True
+    assert cfg["4"]["stages"]["solve"]["kernel"] == "msnap::solve_kernel_twin<5, 10>"      # what the library says it launched
+    assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-9
+    # counters are quoted only for the kernel sources they were taken from: a value comes with its source, a null
+    # with the reason
+    for rec in (d["roofline"], cfg["4"]["stages"]["solve"], d["saturated"]["roofline"]):
+        assert isinstance(rec["traffic_source"], str) and len(rec["traffic_source"]) > 10
+        assert rec["traffic"] is None or "csrc" in rec["traffic_source"]
+    mesh = cfg["3"]["stages"]["mesh"]
+    assert 0.0 < mesh["cull_ratio"] < 1.0 and 0.0 < mesh["frac"] < 1.0 and mesh["frac_on_all_pairs"] > mesh["frac"]
+    ss = d["strong_scaling"]
+    assert ss["n_gpus"] == 1 and {"solve_order9_65536x10", "solve_order7_65536x10", "formation_4096x10",
+                                  "formation_16384x10"} <= set(ss)
+    assert all(ss[k]["value"] > 1e6 for k in ss if isinstance(ss[k], dict))
     assert d["saturated"]["max_norm_rel_err_vs_oracle"] <= 1e-6
     assert d["shared_grid"]["saturated"]["max_norm_rel_err_vs_oracle"] <= 1e-6
     assert d["end_to_end"]["value"] > 0

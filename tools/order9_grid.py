@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Order-9 solve, launch time over the persistent grid ("solve_grid_waves").
+"""The throughput solve (order 9, or PROBE_ORDER=7), launch time over the persistent grid ("solve_grid_waves").
    python tools/order9_grid.py <drones> <segments> <waves> [<waves> ...]"""
 import os
 import sys
@@ -13,7 +13,7 @@ from drone_path_planning_python_amd import Context  # noqa: E402
 from drone_path_planning_python_amd.synthetic import swarm  # noqa: E402
 
 N, M = int(sys.argv[1]), int(sys.argv[2])
-order = 9
+order = int(os.environ.get("PROBE_ORDER", "9"))
 dev = torch.device("cuda", 0)
 wp, t = swarm(5, min(N, 65536), M)
 reps = (N + wp.shape[0] - 1) // wp.shape[0]
@@ -38,5 +38,5 @@ for waves in [int(x) for x in sys.argv[3:]]:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"order 9 {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak", flush=True)
+    print(f"order {order} {N} x {M}: grid {waves or 'default'}: {us:.1f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak", flush=True)
 ctx.close()
