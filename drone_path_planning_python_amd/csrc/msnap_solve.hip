@@ -1719,7 +1719,7 @@ constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance pe
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
 constexpr int kTwinMaxSeg = 12;    // order 9, even n_seg <= 12, batches beyond one wave per CU: solve_kernel_twin (14: 40 B of scratch)
-constexpr int kTwinMaxSeg7 = 18;   // order 7, even n_seg <= 18 (20: 32 B of scratch at 256 registers)
+constexpr int kTwinMaxSeg7 = 20;   // order 7 (19 and 20 segments keep 8-10 dwords in scratch at 256 registers)
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
@@ -1796,7 +1796,7 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
       switch (M) {
         MSNAP_TWIN(4) MSNAP_TWIN(5) MSNAP_TWIN(6) MSNAP_TWIN(7) MSNAP_TWIN(8) MSNAP_TWIN(9) MSNAP_TWIN(10)
         MSNAP_TWIN(11) MSNAP_TWIN(12) MSNAP_TWIN(13) MSNAP_TWIN(14) MSNAP_TWIN(15) MSNAP_TWIN(16) MSNAP_TWIN(17)
-        MSNAP_TWIN(18)
+        MSNAP_TWIN(18) MSNAP_TWIN(19) MSNAP_TWIN(20)
         default: return MSNAP_EINVAL;
       }
     }

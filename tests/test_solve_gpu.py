@@ -603,6 +603,7 @@ def _solve_in_shards(ctx, wp, t, shard):
                                                 (7, 10, 5, True), (7, 4, 3, True), (7, 12, 7, True), (7, 18, 6, True),
                                                 (9, 10, 5, True), (9, 6, 4, True), (9, 12, 5, True),
                                                 (7, 5, 3, True), (7, 7, 4, True), (7, 13, 5, True), (7, 17, 6, True),
+                                                (7, 19, 5, True), (7, 20, 6, True),
                                                 (9, 5, 3, True), (9, 9, 5, True), (9, 11, 4, True)])
 def test_persistent_solve_walks_several_tiles(order, m, waves, shared, twin):
     """The persistent throughput kernels with a grid of `waves` wavefronts -- solve_kernel_reg<4|5, 10|20> (16 drones
@@ -824,7 +825,11 @@ def test_last_kernel_reports_the_launched_instance():
         assert ctx.last_kernel() == "msnap::solve_kernel_twin<4, 7>"       # odd: side 1 owns a knot more
         wp, t = swarm(78, 300, 20)
         ctx.solve_batch(wp, t)
-        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 20>"       # beyond 18 segments: the one-sided register kernel
+        assert ctx.last_kernel() == "msnap::solve_kernel_twin<4, 20>"
+        ctx.set_option("no_twin", 1)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<4, 20>"       # the one-sided register kernel
+        ctx.set_option("no_twin", 0)
         wp, t = swarm(79, 40, 10, shared_times=True)
         ctx.prepare_grid(t)
         ctx.solve_grid(wp)
