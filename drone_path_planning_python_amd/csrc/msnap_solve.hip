@@ -1037,7 +1037,8 @@ __device__ __forceinline__ void store_twin_coalesced(double2 *sTr, double *__res
 
 inline size_t twin_lds_bytes(int khalf, int n_seg) {
   const size_t h = (size_t)(n_seg - 2) - (size_t)(n_seg - 2) / 2;     // knots of the longer side
-  const size_t g_words = h * (size_t)(khalf - 1) * kWave;     // h knots x NU rows x 16 (drone, side) blocks x 4 column slots
+  size_t g_words = h * (size_t)(khalf - 1) * kWave;           // h knots x NU rows x 16 (drone, side) blocks x 4 column slots
+  if (khalf == 4 && n_seg >= 17) g_words += 4 * (size_t)(khalf - 1) * kWave;   // z of the first knots (kTwinZInLds)
   const size_t in_words = (size_t)kTwinDrones * (n_seg + 1) * 5;
   const size_t body = (khalf == 5 ? (size_t)kTwinTrWords : 0) + g_words;
   return (in_words > body ? in_words : body) * sizeof(double);
@@ -1045,6 +1046,11 @@ inline size_t twin_lds_bytes(int khalf, int n_seg) {
 // waves per SIMD an instance is built for (registers: 512 / waves per lane)
 // (registers as built: order 7: 81 / 96 / 124 / 148 / 175 / 202 / 233 / 256 at 4 / 6 / ... / 18 segments; order 9:
 //  92 / 123 / 164 / 201 / 242 at 4 / 6 / 8 / 10 / 12)
+// knots per side whose z lives in LDS (1.5 KB per knot at order 7): the 17- to 20-segment instances -- 19 and 20
+// segments would otherwise keep 23 / 8 dwords in scratch at the 256 registers of two waves per SIMD, 17 and 18 sit
+// exactly at 256 (no kernel of the library uses scratch: tests/test_abi.py)
+template <int K, int M>
+constexpr int kTwinZInLds = (K == 4 && M >= 17) ? 4 : 0;
 template <int K, int M>
 constexpr int kTwinWaves = 2;
 
@@ -1149,6 +1155,10 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
   double *sTraw = sWraw + kTwinDrones * wpitch;
   double2 *sTr = reinterpret_cast<double2 *>(lds);
   double *sG = lds + (NC == 10 ? kTwinTrWords : 0);
+  // the longest instances keep z of their first ZL knots (the ones that wait longest for the backward sweep) in LDS
+  // behind the G slots instead of in registers: [knot][row][64 lanes]
+  constexpr int ZL = kTwinZInLds<K, M>;
+  double *sZ = sG + H * kSlotWords;
   double dsg[NU];
 #pragma unroll
   for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
@@ -1292,8 +1302,13 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
 #pragma unroll
         for (int r = 0; r < NU; ++r) gs[r * kWave] = g[r];
       }
+      if (it <= ZL) {
 #pragma unroll
-      for (int r = 0; r < NU; ++r) zreg[it - 1][r] = y[r];
+        for (int r = 0; r < NU; ++r) sZ[((it - 1) * NU + r) * kWave + lane] = y[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < NU; ++r) zreg[it - 1][r] = y[r];
+      }
 #pragma unroll
       for (int q = 0; q < NU - 1; ++q) {
         g[q] *= xp[NU - 1 - q];
@@ -1382,7 +1397,7 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
           const double2 g01 = gsl[r * (kWave / 2)], g23 = gsl[r * (kWave / 2) + 1];
-          double v = zreg[it >= 1 ? it - 1 : 0][r];
+          double v = (it <= ZL) ? sZ[((it >= 1 ? it - 1 : 0) * NU + r) * kWave + lane] : zreg[it >= 1 ? it - 1 : 0][r];
           v = __builtin_fma(-g01.x, un[0], v);
           v = __builtin_fma(-g01.y, un[1], v);
           v = __builtin_fma(-g23.x, un[2], v);
@@ -1718,8 +1733,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
-constexpr int kTwinMaxSeg = 12;    // order 9, even n_seg <= 12, batches beyond one wave per CU: solve_kernel_twin (14: 40 B of scratch)
-constexpr int kTwinMaxSeg7 = 20;   // order 7 (19 and 20 segments keep 8-10 dwords in scratch at 256 registers)
+constexpr int kTwinMaxSeg = 12;    // order 9, batches beyond one wave per CU: solve_kernel_twin (13-20 segments need scratch at 256
+                                   // registers -- 10-130 dwords -- and win only up to 8192 drones: 8192 x 20 28.1 against 32.4 us; not shipped:
+                                   // no kernel of the library uses scratch)
+constexpr int kTwinMaxSeg7 = 20;   // order 7 (19 and 20 segments: z of the first knots in LDS instead of registers)
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
 
@@ -1737,7 +1754,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   //  65 536: 42.0 / - / 43.4 (eager launches); 2^20: 0.70 ms against 0.634 -- beyond 256 drones per CU the 16-drone
   //  waves of solve_kernel_reg are ahead)
   const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && !ctx->no_twin &&
-                        (ctx->twin_max_drones > 0 ? N <= ctx->twin_max_drones : (K == 5 || N <= ctx->n_cu * 256)));
+                        (ctx->twin_max_drones > 0 ? N <= ctx->twin_max_drones
+                                                   : (K == 5 || N <= ctx->n_cu * 256)));
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
                                                   : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {

@@ -86,3 +86,43 @@ def test_prefetch_wait_counts_match_the_code_object():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_prefetch_isa.py"), obj],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    """Code-object metadata of every kernel in libmsnap.so: .private_segment_fixed_size == 0.  Spilled registers cost
+    memory round trips inside the hot loops, and scratch ties a launch to per-queue state of the runtime (an order-9
+    instance with 188 bytes of scratch aborted inside the HIP runtime when a long-lived stream first needed scratch
+    after short-lived ones had used it): the kernels are built to their register budgets instead."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    lib = os.path.join(ROOT, "drone_path_planning_python_amd", "csrc", "libmsnap.so")
+    if not os.path.exists(lib) or not os.path.exists(f"{llvm}/llvm-readelf"):
+        pytest.skip("no library / ROCm LLVM tools here")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "lib.co")
+        subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(tmp, "copy.so")],
+                       check=True)
+        # libmsnap.so bundles one code object per translation unit
+        raw = open(fat, "rb").read()
+        names, sizes = [], []
+        off = 0
+        while True:
+            k = raw.find(b"__CLANG_OFFLOAD_BUNDLE__", off)
+            if k < 0:
+                break
+            piece = os.path.join(tmp, f"bundle{len(names)}.bin")
+            nxt = raw.find(b"__CLANG_OFFLOAD_BUNDLE__", k + 8)
+            open(piece, "wb").write(raw[k:nxt if nxt > 0 else len(raw)])
+            r = subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={piece}", f"--output={co}"],
+                               capture_output=True, text=True)
+            off = k + 8
+            if r.returncode != 0:
+                continue
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True, check=True).stdout
+            names += re.findall(r"\.name:\s+(\S+)", notes)
+            sizes += [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+    assert len(sizes) >= 100 and len(sizes) == len(names), (len(sizes), len(names))
+    bad = [(n, s) for n, s in zip(names, sizes) if s != 0]
+    assert not bad, bad[:5]
