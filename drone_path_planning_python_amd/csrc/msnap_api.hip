@@ -54,7 +54,7 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
 };
 
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
@@ -74,6 +74,10 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;
   if (!strcmp(name, "collide_no_sym")) return &ctx->collide_no_sym;
+  if (!strcmp(name, "collide_no_cull")) return &ctx->collide_no_cull;
+  if (!strcmp(name, "collide_cull_min_drones")) return &ctx->collide_cull_min_drones;
+  if (!strcmp(name, "collide_last_cull")) return &ctx->collide_last_cull;
+  if (!strcmp(name, "collide_last_shares")) return &ctx->collide_last_shares;
   if (!strcmp(name, "collide_last_sym")) return &ctx->collide_last_sym;   // (read: what the last pass did)
   if (!strcmp(name, "own_stream_priority")) return &ctx->own_stream_priority;   // (read side; set has its own branch)
   return nullptr;
@@ -236,6 +240,18 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
         return MSNAP_EHIP;
     }
     *value = (long)n;
+    return MSNAP_OK;
+  }
+  if (!strcmp(name, "collide_last_survivors")) {   // of the last broad-phase pass (synchronises the stream)
+    int32_t n = 0;
+    if (ctx->collide_last_cull && ctx->collide_meta) {
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+          hipMemcpy(&n, ctx->collide_meta + 64, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+        return MSNAP_EHIP;
+    } else {
+      n = ctx->collide_last_shares;
+    }
+    *value = n;
     return MSNAP_OK;
   }
   const int *slot = option_slot(const_cast<msnap_ctx *>(ctx), name);

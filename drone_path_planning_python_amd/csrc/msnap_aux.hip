@@ -143,7 +143,8 @@ int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const
 // ------------------------------------------------------------------------------------
 constexpr int kRowBlockRows = 128;   // rows per row block of the pairwise pass (kRowBlock below): pitch granularity of its row image
 __global__ void collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t,
-                                         int ny, int32_t *__restrict__ fill, size_t fill_n);
+                                         int ny, int32_t *__restrict__ fill, size_t fill_n, const int32_t *__restrict__ perm,
+                                         double *__restrict__ psorted);
 
 // Generic form: one thread per (drone, sample), the reference's search loop as it stands.  Used for
 // drones whose durations are not all >= 0 (the search is then not a partition into ranges), for
@@ -328,7 +329,8 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
       MSNAP_HIP(ctx, hipGetLastError());
       const int E = n_samples * 3;
       hipLaunchKernelGGL(collide_transpose_kernel, dim3(Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream,
-                         (const double *)pos, n_drones, Rp, E, pos_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
+                         (const double *)pos, n_drones, Rp, E, pos_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0,
+                         (const int32_t *)nullptr, (double *)nullptr);
     }
   }
   MSNAP_HIP(ctx, hipGetLastError());
@@ -627,16 +629,41 @@ struct RowSet {
   int bestj[kRowsPerLane];
 };
 
+// The exact broad phase of a whole-swarm pass (launch_formation_collide, "cull" path).  Rows and columns are walked in
+// a spatially sorted order (Morton order of the drones' path boxes); every 128-row block and every aligned group of 8
+// columns has the bounding box of its drones' finite samples and the largest of its drones' BOUNDS -- a squared
+// distance each drone is known to attain to some other drone (its sorted neighbours, collide_bound_kernel).  A
+// two-sided block whose box distance exceeds both maxima cannot lower any of its rows' or columns' minima -- nor tie
+// them: the test is strict, and the box distance is formed with the pass's own fma formula, so it never exceeds the
+// squared distance of any pair of the two boxes -- and is skipped.  Minima, partners (compared by ORIGINAL index,
+// `oid`) and hits are those of the full pass.
+struct CollideCull {
+  const double *colbox;    // [ceil(N / 8)][6] lo x,y,z / hi x,y,z per aligned group of 8 sorted drones
+  const double *cmax;      // [ceil(N / 8)] largest bound of the group
+};
+
+__device__ __forceinline__ double box_box_lb2(const double *__restrict__ a, const double *__restrict__ b) {
+#pragma clang fp contract(off)
+  double gp[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double g1 = a[k] - b[3 + k], g2 = b[k] - a[3 + k];     // lo_a - hi_b, lo_b - hi_a
+    gp[k] = fmax(0.0, fmax(g1, g2));
+  }
+  return __builtin_fma(gp[2], gp[2], __builtin_fma(gp[1], gp[1], gp[0] * gp[0]));
+}
+
 // One block of NC (even, <= kColBlock) consecutive columns [cj, cj + ncols) against the wave's
 // kRowBlock rows: straight-line code over the columns -- with a branch inside the column loop the
 // scalar register sets cross basic blocks and the compiler copies every fetched value into vector
 // registers (36 extra VALU moves per fetch) -- so a short block takes the next instance up and
 // re-reads its last column instead of branching.
-template <int NC>
+template <int NC, bool CULL = false>
 __device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ prowT,
                                               const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
                                               RowSet &rs, int I, int h, int lane, double *sFold, int *sFoldI,
-                                              double *__restrict__ cpart_d2, int32_t *__restrict__ cpart_i) {
+                                              double *__restrict__ cpart_d2, int32_t *__restrict__ cpart_i,
+                                              const int32_t *__restrict__ oid = nullptr) {
 #pragma clang fp contract(off)
   constexpr int CH = kSampleChunk, RPL = kRowsPerLane;
   const int S = g.S;
@@ -727,16 +754,19 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       }
     }
   }
-  // row side: columns ascend, so the lowest index wins a tie
+  // row side: columns ascend, so the lowest index wins a tie (cull path: sorted order, ties by the ORIGINAL index)
 #pragma unroll
   for (int jj = 0; jj < NC; ++jj) {
     const int j = cj + jj;
+    const int oj = CULL ? oid[jj < ncols ? j : cj] : j;
 #pragma unroll
     for (int rr = 0; rr < RPL; ++rr) {
       acc[rr][jj] = (j == rs.grow[rr] || jj >= ncols) ? INFINITY : acc[rr][jj];
-      if (acc[rr][jj] < rs.best[rr]) {
+      const bool take = CULL ? (acc[rr][jj] < rs.best[rr]) | ((acc[rr][jj] == rs.best[rr]) & (oj < rs.bestj[rr]))
+                             : (acc[rr][jj] < rs.best[rr]);
+      if (take) {
         rs.best[rr] = acc[rr][jj];
-        rs.bestj[rr] = j;
+        rs.bestj[rr] = oj;
       }
     }
   }
@@ -748,16 +778,20 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
     // (The lane index is taken from an opaque copy: left visible, the fold's lane-derived addresses are hoisted
     // out of the share's loops and kept -- in scratch -- across the column loop, whose 128 registers are spoken for.)
     asm volatile("" : "+v"(lane));
+    int orow[RPL];       // cull path: the rows' ORIGINAL indices, fetched here rather than held through the column loop
+#pragma unroll
+    for (int rr = 0; rr < RPL; ++rr) orow[rr] = CULL ? oid[rs.live[rr] ? I * kRowBlock + rr * kWave + lane : g.R - 1] : 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       double v = rs.live[0] ? acc[0][c] : INFINITY;
-      int vi = lane;
+      int vi = CULL ? orow[0] : lane;
 #pragma unroll
       for (int rr = 1; rr < RPL; ++rr) {
         const double o = rs.live[rr] ? acc[rr][c] : INFINITY;
-        if (o < v) {
+        const int oi = CULL ? orow[rr] : lane + rr * kWave;
+        if (o < v || (CULL && o == v && oi < vi)) {
           v = o;
-          vi = lane + rr * kWave;
+          vi = oi;
         }
       }
       sFold[c * kWave + lane] = v;
@@ -792,7 +826,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
     if (part == 0 && c < ncols) {
       const size_t slot = ((size_t)(I - g.I_lo) * g.sparts + h) * g.R + (size_t)(cj + c - g.os);
       cpart_d2[slot] = cm;
-      cpart_i[slot] = (cm == INFINITY) ? -1 : g.ro + I * kRowBlock + ci;
+      cpart_i[slot] = (cm == INFINITY) ? -1 : (CULL ? ci : g.ro + I * kRowBlock + ci);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -803,9 +837,12 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
 // tiles through LDS, read along a drone's samples and written along the rows.
 // Rows of workgroups behind the `ny` of the transposition mark the column-side partner slots of a part launch
 // as empty (-1): a part covers its first and last row block only partly, and the merge skips empty slots.
+// `perm` (cull path): row r of the image is drone perm[r] of prow, and `psorted` receives the same rows drone-major
+// (the column array of the sorted pass), both from one read of the tile.
 __global__ void __launch_bounds__(256)
 collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, double *__restrict__ prow_t, int ny,
-                         int32_t *__restrict__ fill, size_t fill_n) {
+                         int32_t *__restrict__ fill, size_t fill_n, const int32_t *__restrict__ perm,
+                         double *__restrict__ psorted) {
   constexpr int TE = 32;      // elements of a drone per tile (x 64 rows): 2.4 workgroups per CU at 4096 x 91
   __shared__ double tile[64][TE + 1];
   if ((int)blockIdx.y >= ny) {
@@ -820,7 +857,9 @@ collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, 
 #pragma unroll
     for (int i = ty; i < 64; i += 256 / TE) {
       const int r = min(r0 + i, R - 1), e = e0 + tx;
-      tile[i][tx] = e < E ? prow[(size_t)r * E + e] : 0.0;
+      const double v = e < E ? prow[(size_t)(perm ? perm[r] : r) * E + e] : 0.0;
+      tile[i][tx] = v;
+      if (psorted && e < E && r0 + i < R) psorted[(size_t)r * E + e] = v;
     }
   }
   __syncthreads();
@@ -832,10 +871,10 @@ collide_transpose_kernel(const double *__restrict__ prow, int R, int Rp, int E, 
   }
 }
 
-__global__ void __launch_bounds__(kWave, 4)
-collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
-                    double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
-                    int32_t *__restrict__ cpart_i) {
+__device__ __forceinline__ void collide_span_body(const double *__restrict__ prow_t, const double *__restrict__ pcol,
+                                                  const CollideGeom &g, double *__restrict__ part_d2,
+                                                  int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                                                  int32_t *__restrict__ cpart_i) {
   constexpr int CB = kColBlock;
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
@@ -898,6 +937,155 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
   }
 }
 
+__global__ void __launch_bounds__(kWave, 4)
+collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
+                    double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                    int32_t *__restrict__ cpart_i) {
+  collide_span_body(prow_t, pcol, g, part_d2, part_j, cpart_d2, cpart_i);
+}
+
+// ---- the whole-swarm pass with the exact broad phase (CollideCull) ----
+// Sorted order; row block I (rows 128 I ..) meets the columns from its own first one on, in aligned groups of 8:
+// share k of row block I is the columns 128 I + 8 k .. (+ 8); its first 16 shares are the diagonal block (one-sided
+// among the block's own rows, never culled), the others are two-sided and culled by the box test.
+
+// sample parts per surviving share: enough waves to fill the wave slots once, while a part keeps two chunks
+constexpr int kCullMaxParts = 8;
+__device__ __host__ __forceinline__ int cull_sparts(long long tot, int slots, int nch) {
+  int sp = 1;
+  while (sp < kCullMaxParts && tot * sp < slots && nch / (sp * 2) >= 2) sp *= 2;
+  return sp;
+}
+__device__ __host__ __forceinline__ int cull_nch(int S) {
+  const int rem = S % kSampleChunk;
+  const int Sw = (rem == 1 || rem == 2) ? S - rem : S;
+  return (Sw + kSampleChunk - 1) / kSampleChunk;
+}
+
+// One workgroup per row block: thread k tests share k and the survivors' numbers are written, in order, to
+// surv[I][0 .. cnt[I]).
+constexpr int kSelThreads = 1024;
+__global__ void __launch_bounds__(kSelThreads)
+collide_select_kernel(int N, CollideCull cu, int32_t *__restrict__ surv, int maxsh, int32_t *__restrict__ cnt) {
+  constexpr int GPB = kRowBlock / kColBlock;      // groups of 8 per row block
+  __shared__ int wsum[kSelThreads / kWave];
+  __shared__ double sRow[GPB][8];      // the row block's own groups: box, largest bound
+  const int I = blockIdx.x, lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+  const int nsh = (N - I * kRowBlock + kColBlock - 1) / kColBlock;
+  const int ng = nsh < GPB ? nsh : GPB;
+  if (threadIdx.x < 7 * GPB) {
+    const int q = threadIdx.x / 7, k = threadIdx.x % 7;
+    if (q < ng) sRow[q][k] = k < 6 ? cu.colbox[(size_t)(I * GPB + q) * 6 + k] : cu.cmax[I * GPB + q];
+  }
+  __syncthreads();
+  int base = 0;
+  for (int k0 = 0; k0 < nsh; k0 += kSelThreads) {
+    const int k = k0 + threadIdx.x;
+    bool keep = false;
+    if (k < nsh) {
+      keep = true;
+      if (k >= GPB) {
+        // Skip the share unless some pair of it could reach (or tie) a minimum of its row or its column: the rows are
+        // taken group by group -- a block of 128 consecutive drones of the sorted order can straddle a jump of the
+        // curve, its groups of 8 hardly ever do.
+        const int J = I * GPB + k;
+        double cb[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cb[c] = cu.colbox[(size_t)J * 6 + c];
+        const double cm = cu.cmax[J];
+        keep = false;
+        for (int q = 0; q < ng; ++q) {
+          const double lb2 = box_box_lb2(sRow[q], cb);
+          keep |= !((lb2 > sRow[q][6]) & (lb2 > cm));
+        }
+      }
+    }
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = base;
+#pragma unroll
+    for (int q = 0; q < kSelThreads / kWave; ++q) {
+      const int v = wsum[q];
+      off += q < w ? v : 0;
+      base += v;
+    }
+    if (keep) surv[(size_t)I * maxsh + off + __popcll(m & ((1ull << lane) - 1ull))] = k;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[I] = base;
+}
+
+// The surviving shares, walked by a fixed grid of waves: item it = (survivor it / sp, sample part it % sp) in the
+// order of the lists; its row-side partial entry is entry `it` of part_d2 / part_j, the column side goes to the
+// (row block, sample part) slots as in the plain pass.  At most 64 row blocks (kCullMaxDrones): lane I holds the
+// list offset of row block I through LDS.
+__global__ void __launch_bounds__(kWave, 4)
+collide_span_list_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
+                         double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                         int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ surv,
+                         int maxsh, const int32_t *__restrict__ cnt, int sp_force, int slots, int32_t *__restrict__ meta) {
+  constexpr int CB = kColBlock;
+  __shared__ double sFold[CB * kWave];
+  __shared__ int sFoldI[CB * kWave];
+  __shared__ int sPre[kWave];
+  const int lane = threadIdx.x;
+  int tot;
+  {
+    const int c = lane < g.n_rb ? cnt[lane] : 0;
+    int inc = c;
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+      const int o = __shfl_up(inc, m);
+      inc += lane >= m ? o : 0;
+    }
+    sPre[lane] = lane < g.n_rb ? inc - c : 0x7fffffff;
+    tot = __builtin_amdgcn_readlane(inc, kWave - 1);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  g.sparts = sp_force > 0 ? sp_force : cull_sparts(tot, slots, cull_nch(g.S));
+  if (blockIdx.x == 0) {      // for the merge: list offsets [0..63], survivors [64], sample parts [65]
+    meta[lane] = sPre[lane];
+    if (lane == 0) {
+      meta[kWave] = tot;
+      meta[kWave + 1] = g.sparts;
+    }
+  }
+  const int items = tot * g.sparts;      // (at most 33280 shares x kCullMaxParts)
+  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+    const int f = it / g.sparts, h = it - f * g.sparts;
+    const int pre = sPre[lane];
+    const int I = __popcll(__ballot(pre <= f)) - 1;      // the last row block whose list starts at or before f
+    const int k = surv[(size_t)I * maxsh + (f - __builtin_amdgcn_readlane(pre, I))];
+    const int cj = I * kRowBlock + k * CB;
+    const int ncols = g.Cn - cj < CB ? g.Cn - cj : CB;
+    const bool two_sided = k >= kRowBlock / CB;
+    RowSet rs;
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerLane; ++rr) {
+      const int raw = I * kRowBlock + rr * kWave + lane;
+      rs.live[rr] = raw < g.R;
+      rs.grow[rr] = rs.live[rr] ? raw : g.R - 1;
+      rs.best[rr] = INFINITY;
+      rs.bestj[rr] = -1;
+    }
+    const double *prowT = prow_t + (size_t)I * kRowBlock;
+    if (ncols <= 2)
+      collide_block<2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+    else if (ncols <= CB / 2)
+      collide_block<CB / 2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+    else
+      collide_block<CB, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerLane; ++rr) {
+      part_d2[(size_t)it * kRowBlock + rr * kWave + lane] = rs.best[rr];
+      part_j[(size_t)it * kRowBlock + rr * kWave + lane] = (rs.best[rr] == INFINITY) ? -1 : rs.bestj[rr];
+    }
+  }
+}
+
 // paths shorter than one sample chunk: plain loops, one-sided
 __global__ void __launch_bounds__(kWave)
 collide_short_kernel(const double *__restrict__ prow, const double *__restrict__ pcol, int R, int ro, int Cn, int S,
@@ -948,7 +1136,8 @@ constexpr int kMergeParts = 16;
 __global__ void __launch_bounds__(kMergeRows * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
-                     double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
+                     double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit,
+                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta) {
   __shared__ double sD[kMergeParts][kMergeRows];
   __shared__ int sJ[kMergeParts][kMergeRows];
   const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
@@ -977,7 +1166,14 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
       }
     }
   };
-  if (g.total > 0) {
+  if (cnt) {
+    // broad-phase pass (collide_span_list_kernel): the row block's surviving shares are consecutive entries
+    const int I = __builtin_amdgcn_readfirstlane(r / kRowBlock);      // (kMergeRows divides kRowBlock)
+    const int pre = meta[I], sp = meta[kWave + 1];
+    const size_t first = (size_t)pre * sp * kRowBlock + (r - I * kRowBlock);
+    sweep(part_d2 + first, part_j + first, kRowBlock, cnt[I] * sp);
+    if (I > 0) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * sp);
+  } else if (g.total > 0) {
     // row side: the shares of this launch that met this drone's row block
     const int I = r / kRowBlock;
     long long ua = collide_ustart(g, I), ub = collide_ustart(g, I + 1) - 1;      // the row block's units ...
@@ -1010,10 +1206,11 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
       min_dist[r] = best;
       partner[r] = bj;
     } else {
+      const int out = oid ? oid[r] : r;      // cull path: row r of the sorted pass is drone oid[r]
       const double dist = sqrt(best);
-      min_dist[r] = dist;
-      partner[r] = bj;
-      hit[r] = (dist < 2.0 * radius) ? 1 : 0;
+      min_dist[out] = dist;
+      partner[out] = bj;
+      hit[out] = (dist < 2.0 * radius) ? 1 : 0;
     }
   }
 }
@@ -1052,6 +1249,261 @@ __global__ void __launch_bounds__(256) collide_part_clear_kernel(double *__restr
   }
 }
 
+// fp64 min / max over the 64 lanes of a wave (every lane gets the result): four DPP stages inside
+// the rows of 16 (lane xor 1, xor 2, mirror of 8, mirror of 16), two exchanges across the rows
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_f64(double v) {
+  auto fold = [](double a, double b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
+  v = fold(v, dpp_f64<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fold(v, dpp_f64<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fold(v, dpp_f64<0x141>(v));    // row_half_mirror
+  v = fold(v, dpp_f64<0x140>(v));    // row_mirror
+  v = fold(v, __shfl_xor(v, 16));
+  v = fold(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
+__device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
+// The same butterflies with IEEE minNum / maxNum: a NaN operand is ignored, so a wave that mixes NaN and finite
+// values ends with the extreme of the finite ones in EVERY lane (with the compare-and-select fold a lane holding
+// NaN keeps it and its partner drops that subtree: the lanes would disagree); all-NaN stays NaN.
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_num_f64(double v) {
+  auto fold = [](double a, double b) { return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b); };
+  v = fold(v, dpp_f64<0xB1>(v));
+  v = fold(v, dpp_f64<0x4E>(v));
+  v = fold(v, dpp_f64<0x141>(v));
+  v = fold(v, dpp_f64<0x140>(v));
+  v = fold(v, __shfl_xor(v, 16));
+  v = fold(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// the value of lane 0 as a compiler-visible wave-uniform value (after a wave reduction every lane holds
+// the same number, but only this makes the branches and triangle loads that depend on it scalar)
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// ------------------------------------------------------------------------------------
+// The exact broad phase of a whole-swarm pass (CollideCull above): sort keys, sort, bounds and boxes.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long spread3(unsigned long long v) {      // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+
+// per drone (one wavefront each, four to a workgroup: the drone's S x 3 doubles are one coalesced sweep): the box of its
+// finite samples (lo = +inf, hi = -inf when it has none) and the sort key -- the Morton code of the box's centre on a
+// 1 m x 1 m x 4 m lattice (paths are metres; 11 + 11 + 10 bits around the origin, clamped beyond +-1 km: a swarm inside
+// one cell, or far out, sorts arbitrarily and less is culled -- the result does not depend on the order).  Drones
+// without a finite sample get the largest key and sort to the end.
+constexpr int kKeyDrones = 4;
+__global__ void __launch_bounds__(kWave * kKeyDrones)
+collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int d = blockIdx.x * kKeyDrones + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  if (d >= N) return;
+  const double *p = pos + (size_t)d * S * 3;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const int E = S * 3;
+  for (int e0 = 0; e0 < E; e0 += 3 * kWave) {
+    // three elements per lane and trip, 64 apart: element e is coordinate e % 3, and 64 % 3 == 1
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int e = e0 + q * kWave + lane;
+      const double v = e < E ? p[e] : __builtin_nan("");
+      const int k = (lane + q) % 3;           // (e0 is a multiple of 3)
+      if (__builtin_isfinite(v)) {
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+          if (k == kk) {
+            lo[kk] = v < lo[kk] ? v : lo[kk];
+            hi[kk] = v > hi[kk] ? v : hi[kk];
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = uniform_f64(wave_minmax_f64<false>(lo[k]));
+    hi[k] = uniform_f64(wave_minmax_f64<true>(hi[k]));
+  }
+  if (lane < 3) {
+    box[(size_t)d * 6 + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lo[2];
+    box[(size_t)d * 6 + 3 + lane] = lane == 0 ? hi[0] : lane == 1 ? hi[1] : hi[2];
+  }
+  if (lane == 0) {
+    unsigned long long kk = 0xffffffffull;
+    if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+      const double cell[3] = {1.0, 1.0, 4.0}, half[3] = {1024.0, 1024.0, 512.0};
+      unsigned long long q[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double c = floor(0.5 * (lo[k] + hi[k]) / cell[k]) + half[k];
+        c = c < 0.0 ? 0.0 : (c > 2.0 * half[k] - 1.0 ? 2.0 * half[k] - 1.0 : c);
+        q[k] = (unsigned long long)c;
+      }
+      kk = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);      // < 2^32 (z has 10 bits)
+    }
+    key[d] = (unsigned)kk;
+  }
+}
+
+// The sort, as a rank count spread over the chip: drones are ordered by (key, index) -- all distinct -- so the sorted
+// position of drone i is the number of drones below it.  One workgroup of 16 wavefronts per 64 drones: wavefront w
+// counts over the w-th sixteenth of the keys (wave-uniform: scalar loads, one 32-bit compare and one add-with-carry
+// per key: "key_j <= key_i" for the drones before the wavefront's own 64, "<" behind them, the pair compare among
+// them), the sixteen counts are added through LDS.  N^2 compares -- 17 M at 4096 drones, a few us over 64 CUs --
+// against the 78 dependent stages of a sorting network on one CU (36 us measured).
+// perm[sorted position] = original index.
+constexpr int kCullMaxDrones = 8192;
+constexpr int kCullMinDrones = 3072;
+constexpr int kRankWaves = 16;
+__global__ void __launch_bounds__(kWave * kRankWaves)
+collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict__ perm) {
+  __shared__ int cnt[kRankWaves][kWave];
+  const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int i0 = blockIdx.x * kWave, i = i0 + lane;
+  const unsigned ki = i < N ? key[i] : 0xffffffffu;
+  const int per = ((N + kRankWaves - 1) / kRankWaves + 15) & ~15;
+  const int j0 = w * per < N ? w * per : N, j1 = (j0 + per < N) ? j0 + per : N;
+  int c = 0;
+  auto count = [&](int a, int b, auto below) {      // keys [a, b)
+    int j = a;
+    // (64 keys per trip: four wide scalar loads in flight -- with one the loop is a chain of their latencies)
+    for (; j + 64 <= b; j += 64) {
+#pragma unroll
+      for (int q = 0; q < 64; ++q) c += below(key[j + q], j + q) ? 1 : 0;
+    }
+    for (; j + 16 <= b; j += 16) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) c += below(key[j + q], j + q) ? 1 : 0;
+    }
+    for (; j < b; ++j) c += below(key[j], j) ? 1 : 0;
+  };
+  const int ia = i0 < j1 ? (i0 > j0 ? i0 : j0) : j1;                     // [j0, ia): before the tile
+  const int ib = i0 + kWave < j1 ? (i0 + kWave > ia ? i0 + kWave : ia) : j1;   // [ia, ib): inside it
+  count(j0, ia, [&](unsigned kj, int) { return kj <= ki; });
+  count(ia, ib, [&](unsigned kj, int j) { return kj < ki || (kj == ki && j < i); });
+  count(ib, j1, [&](unsigned kj, int) { return kj < ki; });
+  cnt[w][lane] = c;
+  __syncthreads();
+  if (w == 0 && i < N) {
+    int r = 0;
+#pragma unroll
+    for (int q = 0; q < kRankWaves; ++q) r += cnt[q][lane];
+    perm[r] = i;
+  }
+}
+
+// One workgroup (1024 threads: 64 rows x 16 sample groups) per 64 drones of the SORTED order.  For sorted drone r:
+//   bound[r]  = min over its sorted neighbours r +- 1..4 and 32 of the common samples (every ceil(S / 32)-th) of the
+//               pass's own squared distance (fma(dz, dz, fma(dy, dy, dx dx)); non-finite samples never win): a value
+//               the drone's final minimum cannot exceed -- ANY subset of its pair-samples bounds it, which is also why
+//               the pairs across a workgroup boundary are simply left out.  Each pair (r, r + k) is evaluated by its
+//               lower row.  A drone without a finite sample contributes 0 to the maxima below (its own result is
+//               +inf / -1 whatever is evaluated, and it is invisible to the others).
+//   colbox[J], cmax[J]      per aligned group of 8 drones: union of their boxes, largest of their bounds
+// A wavefront is one sample group: two samples, 30 loads, all in flight at once -- the kernel is load latency.
+constexpr int kBoundRows = 64;
+constexpr int kBoundGroups = 16;
+constexpr int kBoundReach = 4;
+__global__ void __launch_bounds__(kBoundRows * kBoundGroups)
+collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, const double *__restrict__ box,
+                     const int32_t *__restrict__ perm, double *__restrict__ colbox, double *__restrict__ cmax) {
+#pragma clang fp contract(off)
+  static_assert(kBoundRows == kWave, "a sample group is one wavefront");
+  __shared__ double sf[kBoundReach][kBoundGroups][kBoundRows];
+  __shared__ double sF[kBoundReach][kBoundRows];
+  const int t = threadIdx.x & (kBoundRows - 1), sg = __builtin_amdgcn_readfirstlane(threadIdx.x / kBoundRows);
+  const int r = blockIdx.x * kBoundRows + t;
+  const bool live = r < N;
+  const int rc = live ? r : N - 1;
+  // the drone's box, for the last step: fetched first, it arrives under the sample loads
+  double g8[7];
+  if (sg == 0) {
+    const int o = perm[rc];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g8[k] = box[(size_t)o * 6 + k];
+  }
+  const int stride = (S + 2 * kBoundGroups - 1) / (2 * kBoundGroups);
+  double f[kBoundReach];
+#pragma unroll
+  for (int k = 0; k < kBoundReach; ++k) f[k] = INFINITY;
+  double p[2][kBoundReach + 1][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int sq = (sg + i * kBoundGroups) * stride;
+    sq = sq < S ? sq : S - 1;      // (a sample seen twice does not change a minimum)
+    const double *px = prow_t + (size_t)sq * 3 * Rp;
+#pragma unroll
+    for (int k = 0; k <= kBoundReach; ++k) {
+      const int q = rc + k < N ? rc + k : N - 1;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) p[i][k][c] = px[(size_t)c * Rp + q];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int k = 1; k <= kBoundReach; ++k) {
+      const double dx = p[i][k][0] - p[i][0][0], dy = p[i][k][1] - p[i][0][1], dz = p[i][k][2] - p[i][0][2];
+      const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+      f[k - 1] = __builtin_fmin((live && r + k < N) ? d2 : INFINITY, f[k - 1]);
+    }
+#pragma unroll
+  for (int k = 0; k < kBoundReach; ++k) sf[k][sg][t] = f[k];
+  __syncthreads();
+  if (sg < kBoundReach) {      // wavefront k folds the pairs (r, r + k + 1) over the sample groups
+    double v = sf[sg][0][t];
+#pragma unroll 4
+    for (int q = 1; q < kBoundGroups; ++q) v = __builtin_fmin(v, sf[sg][q][t]);
+    sF[sg][t] = v;
+  }
+  __syncthreads();
+  if (sg == 0) {      // (one whole wavefront from here on)
+    double b = INFINITY;
+#pragma unroll
+    for (int k = 1; k <= kBoundReach; ++k) {
+      b = __builtin_fmin(b, sF[k - 1][t]);
+      if (t >= k) b = __builtin_fmin(b, sF[k - 1][t - k]);
+    }
+    if (!live) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) g8[k] = k < 3 ? INFINITY : -INFINITY;
+    }
+    const bool empty = !(g8[0] <= g8[3]);
+    g8[6] = (!live || empty) ? 0.0 : b;
+    // per aligned group of 8 lanes (8 consecutive threads are 8 consecutive sorted drones)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      auto fold = [k](double a, double c) { return k < 3 ? fmin(a, c) : fmax(a, c); };
+      g8[k] = fold(g8[k], dpp_f64<0xB1>(g8[k]));      // lane xor 1
+      g8[k] = fold(g8[k], dpp_f64<0x4E>(g8[k]));      // lane xor 2
+      g8[k] = fold(g8[k], dpp_f64<0x141>(g8[k]));     // mirror inside the half-row of 8
+    }
+    const int J = r / kColBlock;
+    if (live && (t & 7) == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) colbox[(size_t)J * 6 + k] = g8[k];
+      cmax[J] = g8[6];
+    }
+  }
+}
+
 // `rows_t`: the rows' transposed image [n_samples][3][row pitch] when the caller already has it (the sampler's
 // second output, msnap_sample_collide); nullptr: built here from pos_rows
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
@@ -1079,7 +1531,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     g.total = 0;
     hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
-                       (const int32_t *)nullptr, radius, min_dist, partner, hit);
+                       (const int32_t *)nullptr, radius, min_dist, partner, hit, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
@@ -1142,6 +1595,72 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // columns are one dependent chain of scalar fetches, 43 us at 512 drones whatever the arithmetic.  While the
   // shares do not fill a quarter of the wave slots (half-full launches lose: 512 of 4096 rows 71 -> 84 us), each
   // is taken by 2, 4 or 8 waves with a range of the sample chunks each (narrower column blocks instead would repeat the row loads per block: 1024 drones 46 -> 59 us).
+  // the exact broad phase (CollideCull): a whole swarm, sorted on the GPU
+  // (below some 3000 drones the six small launches in front of the pass cost more than a sparse swarm saves:
+  // 2048 x 91 dense 91 -> 121 us, sparse 92 -> 84; 4096 x 91 dense 243 -> 282, sparse 243 -> 122, the formation
+  // fixture 243 -> 105)
+  const int cull_min = ctx->collide_cull_min_drones > 0 ? ctx->collide_cull_min_drones : kCullMinDrones;
+  const bool cull = g.sym && row_offset == 0 && n_rows == n_cols && !ctx->collide_no_cull && n_rows >= cull_min &&
+                    n_rows >= 2 * kRowBlock && n_rows <= kCullMaxDrones;
+  ctx->collide_last_cull = cull ? 1 : 0;
+  ctx->collide_last_shares = (int)(waves < 0x7fffffff ? waves : 0x7fffffff);
+  const int E = n_samples * 3;
+  if (cull) {
+    // Buffers: sorted row image [E][Rp] | sorted columns [N][E] | box [N][6] | colbox [nJ][6] | cmax [nJ] | row-side entries (d2) | column-side slots (d2) || row-side entries (j) |
+    // column-side slots (j, pre-filled -1) | sort keys [N] | perm [N] | surv [n_rb][maxsh] | cnt [n_rb] | meta [66]
+    const int N = n_rows;
+    const size_t nJ = ((size_t)N + kColBlock - 1) / kColBlock;
+    const int maxsh = (int)nJ;
+    long long shares = 0;
+    for (int I = 0; I < g.n_rb; ++I) shares += (N - I * kRowBlock + kColBlock - 1) / kColBlock;
+    const int spmax = kCullMaxParts;
+    ctx->collide_last_shares = (int)shares;
+    const int sp_force = ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0;
+    // row-side entries: one per item; cull_sparts doubles the parts only while the items do not fill the slots
+    const long long items_max = sp_force ? shares * sp_force : (shares > 2 * slots ? shares : 2 * slots);
+    const size_t entries = (size_t)items_max * kRowBlock;
+    const size_t centries = (size_t)g.n_rb * spmax * N;
+    const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries;
+    const size_t ints = entries + centries + (size_t)N /* sort keys */ + (size_t)N +
+                        (size_t)g.n_rb * maxsh + g.n_rb + kWave + 2;
+    int rc = ensure(ctx, ctx->stage[7], doubles * sizeof(double) + ints * sizeof(int32_t) + 64);
+    if (rc) return rc;
+    double *rows_t = (double *)ctx->stage[7].p;
+    double *psorted = rows_t + (size_t)g.Rp * E, *box = psorted + (size_t)N * E, *colbox = box + (size_t)N * 6;
+    double *cmax = colbox + nJ * 6;
+    double *pd = cmax + nJ, *cd = pd + entries;
+    int32_t *pj = (int32_t *)(cd + centries), *ci = pj + entries;
+    unsigned *key = (unsigned *)(ci + centries);
+    int32_t *perm = (int32_t *)(key + N), *surv = perm + N, *cnt = surv + (size_t)g.n_rb * maxsh, *meta = cnt + g.n_rb;
+    ctx->collide_meta = meta;
+    hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
+                       ctx->stream, pos_cols, N, n_samples, box, key);
+    MSNAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(collide_rank_kernel, dim3((N + kWave - 1) / kWave), dim3(kWave * kRankWaves), 0, ctx->stream,
+                       (const unsigned *)key, N, perm);
+    MSNAP_HIP(ctx, hipGetLastError());
+    const int ny = (E + 31) / 32;
+    hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, ny + 4), dim3(256), 0, ctx->stream, pos_cols, N, g.Rp, E,
+                       rows_t, ny, ci, centries, (const int32_t *)perm, psorted);
+    MSNAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(collide_bound_kernel, dim3((N + kBoundRows - 1) / kBoundRows), dim3(kBoundRows * kBoundGroups), 0,
+                       ctx->stream, (const double *)rows_t, g.Rp, N, n_samples, (const double *)box, (const int32_t *)perm,
+                       colbox, cmax);
+    MSNAP_HIP(ctx, hipGetLastError());
+    CollideCull cu{colbox, cmax};
+    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb), dim3(kSelThreads), 0, ctx->stream, N, cu, surv, maxsh, cnt);
+    MSNAP_HIP(ctx, hipGetLastError());
+    const long long grid = shares * spmax < slots ? shares * spmax : slots;
+    hipLaunchKernelGGL(collide_span_list_kernel, dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
+                       (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, maxsh,
+                       (const int32_t *)cnt, sp_force, (int)slots, meta);
+    MSNAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
+                       ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)perm,
+                       (const int32_t *)cnt, (const int32_t *)meta);
+    MSNAP_HIP(ctx, hipGetLastError());
+    return MSNAP_OK;
+  }
   if (ctx->collide_sample_parts > 0) {
     g.sparts = ctx->collide_sample_parts < 8 ? ctx->collide_sample_parts : 8;
   } else if (ctx->collide_waves_per_cu == 0) {
@@ -1151,7 +1670,6 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   if (upw > 0x3fffffff || waves * g.sparts > 0x7fffffff) return MSNAP_EINVAL;
   const size_t part_entries = ((size_t)waves + g.n_rb) * g.sparts * kRowBlock;
   const size_t centries = g.sym ? cpart_entries * g.sparts : 0;
-  const int E = n_samples * 3;
   const size_t t_entries = rows_t_in ? 0 : (size_t)g.Rp * E;
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
@@ -1163,14 +1681,16 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   int32_t *ci = pj + part_entries;
   if (!rows_t_in) {
     hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream, pos_rows,
-                       n_rows, g.Rp, E, rows_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0);
+                       n_rows, g.Rp, E, rows_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0, (const int32_t *)nullptr,
+                       (double *)nullptr);
     MSNAP_HIP(ctx, hipGetLastError());
   }
   hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
                      rows_t_in ? rows_t_in : (const double *)rows_t, pos_cols, g, pd, pj, cd, ci);
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
-                     ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit);
+                     ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)nullptr,
+                     (const int32_t *)nullptr, (const int32_t *)nullptr);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
@@ -1258,6 +1778,7 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   const int E = n_samples * 3;
   const size_t t_entries = (size_t)g.Rp * E;
   if ((part_entries + centries) * 12 > ((size_t)16 << 30)) return MSNAP_ENOMEM;
+  ctx->collide_last_cull = 0;      // (the buffer the last broad-phase pass left its counts in is reused)
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
@@ -1271,7 +1792,8 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
     const int r_cnt = (N - r_first) < g.Rp ? (N - r_first) : g.Rp;
     const int ny = (E + 31) / 32;
     hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, ny + 4), dim3(256), 0, ctx->stream,
-                       pos_all + (size_t)r_first * E, r_cnt, g.Rp, E, rows_t, ny, ci, centries);
+                       pos_all + (size_t)r_first * E, r_cnt, g.Rp, E, rows_t, ny, ci, centries, (const int32_t *)nullptr,
+                       (double *)nullptr);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_span_kernel, dim3((unsigned)(waves * g.sparts)), dim3(kWave), 0, ctx->stream,
                        (const double *)rows_t, pos_all, g, pd, pj, cd, ci);
@@ -1280,7 +1802,8 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
     g.total = 0;   // the merge of nothing: +inf / -1 everywhere
   }
   hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
-                     ctx->stream, pd, pj, g, cd, ci, 0.0, out_d2, out_j, (int32_t *)nullptr);
+                     ctx->stream, pd, pj, g, cd, ci, 0.0, out_d2, out_j, (int32_t *)nullptr, (const int32_t *)nullptr,
+                     (const int32_t *)nullptr, (const int32_t *)nullptr);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
@@ -1356,49 +1879,6 @@ __device__ __forceinline__ double pt_tri_d2(double px, double py, double pz, con
   }
   const double ex = px - qx, ey = py - qy, ez = pz - qz;
   return ex * ex + ey * ey + ez * ez;
-}
-
-// fp64 min / max over the 64 lanes of a wave (every lane gets the result): four DPP stages inside
-// the rows of 16 (lane xor 1, xor 2, mirror of 8, mirror of 16), two exchanges across the rows
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-template <bool MAX>
-__device__ __forceinline__ double wave_minmax_f64(double v) {
-  auto fold = [](double a, double b) { return MAX ? ((b > a) ? b : a) : ((b < a) ? b : a); };
-  v = fold(v, dpp_f64<0xB1>(v));     // quad_perm [1,0,3,2]
-  v = fold(v, dpp_f64<0x4E>(v));     // quad_perm [2,3,0,1]
-  v = fold(v, dpp_f64<0x141>(v));    // row_half_mirror
-  v = fold(v, dpp_f64<0x140>(v));    // row_mirror
-  v = fold(v, __shfl_xor(v, 16));
-  v = fold(v, __shfl_xor(v, 32));
-  return v;
-}
-__device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
-__device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
-// The same butterflies with IEEE minNum / maxNum: a NaN operand is ignored, so a wave that mixes NaN and finite
-// values ends with the extreme of the finite ones in EVERY lane (with the compare-and-select fold a lane holding
-// NaN keeps it and its partner drops that subtree: the lanes would disagree); all-NaN stays NaN.
-template <bool MAX>
-__device__ __forceinline__ double wave_minmax_num_f64(double v) {
-  auto fold = [](double a, double b) { return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b); };
-  v = fold(v, dpp_f64<0xB1>(v));
-  v = fold(v, dpp_f64<0x4E>(v));
-  v = fold(v, dpp_f64<0x141>(v));
-  v = fold(v, dpp_f64<0x140>(v));
-  v = fold(v, __shfl_xor(v, 16));
-  v = fold(v, __shfl_xor(v, 32));
-  return v;
-}
-
-// the value of lane 0 as a compiler-visible wave-uniform value (after a wave reduction every lane holds
-// the same number, but only this makes the branches and triangle loads that depend on it scalar)
-__device__ __forceinline__ double uniform_f64(double v) {
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                          __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 // squared distance between the box [lo, hi] and the bounding box of triangle t: a lower bound of every

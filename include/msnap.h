@@ -101,6 +101,15 @@ int msnap_host_free(void *ptr);
  *   "collide_no_sym"       1: the rows handed to msnap_formation_collide are not the slice of its columns at
  *                          row_offset -- every pair is evaluated one-sidedly (read-only companion
  *                          "collide_last_sym": 1 if the last pass evaluated its own-range pairs once)
+ *   "collide_cull_min_drones"  smallest whole swarm that takes the exact broad phase (0 = default 3072; at least
+ *                          256: tests lower it to check the path against the oracle on small swarms)
+ *   "collide_no_cull"      1: whole-swarm passes (row_offset 0, n_rows == n_cols, 3072..8192 drones) skip the exact
+ *                          broad phase -- spatial sort, per-drone bounds, box test per 8-column share -- and
+ *                          evaluate every pair; results are identical either way (a dense swarm, where nothing
+ *                          can be culled, saves the sort: about a sixth of the pass at 4096 drones).  Read-only
+ *                          companions: "collide_last_cull" (1 if the last pass took the broad phase),
+ *                          "collide_last_shares" (its shares before the test) and "collide_last_survivors"
+ *                          (the shares it evaluated; synchronises the stream)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
@@ -113,7 +122,8 @@ int msnap_host_free(void *ptr);
  *                          set it BEFORE msnap_get_stream() hands the handle to anybody (a wrapper around
  *                          the old handle -- e.g. torch.cuda.ExternalStream -- would dangle)
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
- * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU and
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
+ * MSNAP_COLLIDE_SAMPLE_PARTS, MSNAP_COLLIDE_NO_CULL, MSNAP_COLLIDE_CULL_MIN_DRONES and
  * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
 int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value);

@@ -201,3 +201,80 @@ def test_collide_in_parts_equals_the_oracle(ctx7, n, S, parts):
     md4, p4, _ = ctx7.formation_collide_finish(blocks4, n, 0.3)
     np.testing.assert_array_equal(md4, ref[0])
     np.testing.assert_array_equal(p4, ref[1])
+
+
+def _broad_phase_swarm(kind, n, S, rng):
+    """Swarms that stress the exact broad phase: what it may skip, and what it must not."""
+    if kind == "dense":            # nothing can be culled
+        return rng.uniform(-2.0, 2.0, size=(n, S, 3))
+    if kind == "sparse":           # far-apart drones that wander a little: most shares are culled
+        start = rng.uniform(-150.0, 150.0, size=(n, 1, 3)) * np.array([1.0, 1.0, 0.05])
+        return start + np.cumsum(rng.normal(0.0, 0.05, size=(n, S, 3)), axis=1)
+    if kind == "teams":            # rigid teams of 8 on a lattice: exact ties between partners, across groups too
+        centre = np.round(rng.uniform(-60.0, 60.0, size=(n // 8 + 1, 1, 3)))
+        drift = np.cumsum(np.round(rng.normal(0.0, 0.6, size=(n // 8 + 1, S, 3))) * 0.25, axis=1)
+        off = np.array([[dx, dy, dz] for dx in (0.0, 0.5) for dy in (0.0, 0.5) for dz in (0.0, 0.5)])
+        pos = (centre + drift)[:, None] + off[None, :, None, :]
+        return pos.reshape(-1, S, 3)[rng.permutation((n // 8 + 1) * 8)[:n]]
+    if kind == "far":              # beyond the +-1 km of the sort lattice, with a crossing pair and a far-away loner
+        pos = 5000.0 + rng.uniform(-300.0, 300.0, size=(n, 1, 3)) + np.cumsum(rng.normal(0.0, 0.1, size=(n, S, 3)), axis=1)
+        pos[5] = pos[n - 3] + 0.01
+        pos[7] = -8000.0
+        return pos
+    raise ValueError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,S", [("dense", 300, 19), ("sparse", 256, 91), ("sparse", 1000, 37), ("sparse", 2049, 13),
+                                      ("teams", 777, 24), ("teams", 1536, 91), ("far", 600, 30), ("sparse", 513, 6),
+                                      ("teams", 3072, 12)])
+def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
+    """The whole-swarm pass behind its exact broad phase (spatial sort, per-drone bounds, box test per 8-column share,
+    surviving shares only): distances, partners and hits bit for bit those of the oracle's all-pairs pass -- with failed
+    drones (NaN paths), drones with a few NaN samples, coincident drones and lattice ties whose partner is decided by the
+    ORIGINAL index -- and of the pass without the broad phase."""
+    rng = np.random.default_rng(77 * n + S)
+    pos = _broad_phase_swarm(kind, n, S, rng)
+    pos[11] = np.nan                                   # a failed drone
+    pos[n // 2, S // 3:S // 3 + 2] = np.nan            # two missing samples
+    pos[n - 1] = pos[3]                                # coincident paths: distance 0, each the other's partner
+    ref = c_oracle.formation_collide(pos, 0.3)
+    ctx7.set_option("collide_cull_min_drones", 256)
+    try:
+        got = ctx7.formation_collide(pos, pos, 0.3)
+        assert ctx7.get_option("collide_last_cull") == 1
+        shares, survivors = ctx7.get_option("collide_last_shares"), ctx7.get_option("collide_last_survivors")
+        for sp in (1, 3, 8):
+            ctx7.set_option("collide_sample_parts", sp)
+            forced = ctx7.formation_collide(pos, pos, 0.3)
+            for a, b in zip(forced, ref):
+                np.testing.assert_array_equal(a, b)
+        ctx7.set_option("collide_sample_parts", 0)
+        ctx7.set_option("collide_no_cull", 1)
+        plain = ctx7.formation_collide(pos, pos, 0.3)
+        assert ctx7.get_option("collide_last_cull") == 0
+    finally:
+        ctx7.set_option("collide_no_cull", 0)
+        ctx7.set_option("collide_sample_parts", 0)
+        ctx7.set_option("collide_cull_min_drones", 0)
+    for a, b, c in zip(got, ref, plain):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(c, b)
+    assert got[0][3] == 0.0 and got[0][n - 1] == 0.0
+    assert 0 < survivors <= shares
+    if kind == "sparse" and n >= 1000:
+        assert survivors < shares * 3 // 4, (survivors, shares)     # the broad phase does cull
+    if kind == "dense":
+        assert survivors > shares * 9 // 10
+
+
+@pytest.mark.gpu
+def test_broad_phase_is_the_default_for_a_whole_large_swarm_only(ctx7):
+    rng = np.random.default_rng(5)
+    pos = _broad_phase_swarm("sparse", 3072, 7, rng)
+    ctx7.formation_collide(pos, pos, 0.3)
+    assert ctx7.get_option("collide_last_cull") == 1
+    ctx7.formation_collide(pos[:2048], pos[:2048], 0.3)
+    assert ctx7.get_option("collide_last_cull") == 0          # small swarm
+    ctx7.formation_collide(pos[:3071], pos, 0.3)
+    assert ctx7.get_option("collide_last_cull") == 0          # a shard, not the whole swarm

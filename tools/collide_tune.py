@@ -22,7 +22,14 @@ def main():
     RO = int(sys.argv[4]) if len(sys.argv) > 4 else 0         # its first global row
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(5)
-    pos = torch.from_numpy(rng.uniform(-50, 50, size=(N, S, 3))).to(dev)
+    if os.environ.get("SPREAD"):
+        # a sparse swarm: start points over a square of SPREAD metres, each drone wanders a couple of metres
+        ext = float(os.environ["SPREAD"])
+        start = rng.uniform(-ext / 2, ext / 2, size=(N, 1, 3)) * np.array([1.0, 1.0, 0.05])
+        pos = torch.from_numpy(start + np.cumsum(rng.normal(0, 0.05, size=(N, S, 3)), axis=1)).to(dev)
+    else:
+        # the dense worst case: every sample anywhere in a 100 m cube (nothing can be culled)
+        pos = torch.from_numpy(rng.uniform(-50, 50, size=(N, S, 3))).to(dev)
     md = torch.empty((R,), dtype=torch.float64, device=dev)
     partner = torch.empty((R,), dtype=torch.int32, device=dev)
     hit = torch.empty((R,), dtype=torch.int32, device=dev)
@@ -52,6 +59,9 @@ def main():
             alg = (R * (N - R) + R * (R - 1) / 2) * S * 7      # 3 differences, 1 product, 2 FMAs, 1 minimum
             print(json.dumps({"N": N, "S": S, "rows": R, "waves_per_cu": wpc, "us": round(us, 1),
                               "frac_of_f64_issue_peak_on_unordered_pairs": round(alg / (us * 1e-6) / VALU_F64_OPS, 3),
+                              "broad_phase": bool(ctx.get_option("collide_last_cull")),
+                              "shares": ctx.get_option("collide_last_shares"),
+                              "survivors": ctx.get_option("collide_last_survivors"),
                               "same_result": bool(same)}), flush=True)
     ctx.close()
 
