@@ -35,6 +35,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   strong_scaling  total work fixed and sharded over the ranks (what a SCALE curve over N should be read
                from; `value` is the 256-drone-per-GPU config of the metric and scales trivially):
                configs[4], 65536 x 10 at order 7, the 4096-drone and a 16384-drone formation pipeline
+               (one GPU: the 4096-drone pipeline also with the pairwise pass's broad phase off)
   saturated    the solve kernel on a batch large enough to fill the chip (2^20 drones), with its
                own roofline fraction and the parity of its first and last 4096 drones against
                the C oracle -- the 256-drone headline is launch/latency-bound by construction
@@ -472,6 +473,9 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
     k1_kernel = ctx.last_kernel()
     pair_once = bool(ctx.get_option("collide_last_sym")) if world == 1 else True   # (parts: by construction)
+    # one rank, a whole swarm of 3072..8192 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
+    broad = bool(ctx.get_option("collide_last_cull")) if world == 1 else False
+    shares, survivors = (ctx.get_option("collide_last_shares"), ctx.get_option("collide_last_survivors")) if broad else (0, 0)
     mesh_extra = None
     if cfg == 3:
         # how many point-triangle tests the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
@@ -496,6 +500,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     # what a rank evaluates: 1 / world of the swarm's (128-row block, column) units, each pair of them once; inside the
     # diagonal blocks both orders of a pair are computed (a 128 x 128 block instead of its triangle)
     pair_exec = (N * (N - 1) / 2 + 64.0 * N) / world * S * PAIR_OPS
+    if broad:       # the surviving shares: 128 rows x 8 columns each
+        pair_exec = survivors * 128.0 * 8.0 * S * PAIR_OPS
     rep = {
         "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
@@ -521,20 +527,30 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                           "time grids takes), outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "pairwise": {"kernel": ("msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)"
+            "pairwise": {"kernel": (("msnap::collide_key_kernel + collide_rank_kernel + collide_transpose_kernel + "
+                                     "collide_bound_kernel + collide_select_kernel + collide_span_list_kernel + "
+                                     "collide_merge_kernel (exact broad phase; the same arithmetic on the surviving shares)"
+                                     if broad else
+                                     "msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)")
                                     if world == 1 else "msnap::collide_transpose_kernel + collide_span_kernel + "
                                     "collide_merge_kernel on this rank's part of the swarm's pairs"),
                          "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": pair_once,
-                         "frac": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
-                         "frac_executed": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
-                         "tflops": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
-                         "frac_of_attainable": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS / PAIR_MIX_ATTAINABLE,
-                         "note": "frac counts each unordered pair once (N(N-1)/2 x S x 7 vector instructions: 3 "
-                                 "differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md 8d) against "
-                                 "the fp64 issue peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); tflops counts the same "
-                                 "work as 9 flops per pair-sample (peak 78.6 with nothing but FMAs), "
-                                 "per GPU; frac_executed counts the pair-samples the kernel evaluates; frac_of_attainable divides "
-                                 "frac by what the bare instruction mix reaches (0.897: tools/micro/f64_rate_micro.hip)"},
+                         "broad_phase": ({"shares": shares, "shares_evaluated": survivors,
+                                          "cull_ratio": survivors / shares} if broad else None),
+                         # the work the kernels evaluate (with the broad phase: the surviving shares) over time and peak
+                         "frac": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
+                         "frac_on_all_pairs": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
+                         "tflops_on_all_pairs": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
+                         "frac_of_attainable": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS / PAIR_MIX_ATTAINABLE,
+                         "note": "frac = the pair-samples the kernels evaluate (N(N-1)/2 + the doubled triangle of the "
+                                 "diagonal blocks; behind the broad phase: 128 x 8 per surviving share) x 7 vector "
+                                 "instructions (3 differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md "
+                                 "8d) / the stage's time -- sort, bounds, selection and merge included -- / the fp64 issue "
+                                 "peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); frac_on_all_pairs credits every unordered "
+                                 "pair once, culled or not (it may exceed 1 behind the broad phase); tflops_on_all_pairs "
+                                 "counts that as 9 flops per pair-sample (peak 78.6 with nothing but FMAs), per GPU; "
+                                 "frac_of_attainable divides frac by what the bare instruction mix reaches (0.897: "
+                                 "tools/micro/f64_rate_micro.hip)"},
         },
     }
     if world > 1:
@@ -692,15 +708,28 @@ def main():
         if not args.no_strong:
             s7 = run_solve_config(env, 65536, 10, 7, reps, 40, "65536 x 10, order 7")
             big = run_formation_config(2, env, max(5, reps // 5), 5, n_groups=2048)
+            c2_all = None
+            if world == 1:      # the one-GPU pass without its broad phase: the arithmetic the sharded pass divides
+                ctx7.set_option("collide_no_cull", 1)
+                try:
+                    c2_all = run_formation_config(2, env, reps, 10)
+                finally:
+                    ctx7.set_option("collide_no_cull", 0)
             if rank == 0:
                 def brief(c):
                     return {"workload": c["workload"], "sharding": c["sharding"], "value": c["value"], "unit": c["unit"],
                             "us_per_pipeline": c["us_per_pipeline"], "stage_us": c["stage_us"]}
                 strong = {"n_gpus": world,
                           "note": "total work fixed and sharded by drone over the ranks; value = drones / max-over-ranks time; "
-                                  "the formation pipelines include both collectives of the pairwise pass",
+                                  "the formation pipelines include both collectives of the pairwise pass.  One GPU runs a "
+                                  "whole swarm of 3072..8192 drones behind the exact broad phase of the pairwise pass "
+                                  "(formation_4096x10); the sharded pass evaluates every pair, 1 / n_gpus of them per rank, "
+                                  "so its curve starts from formation_4096x10_all_pairs -- and at 4096 drones one GPU "
+                                  "behind the broad phase is faster than two or four ranks with their two collectives",
                           "solve_order9_65536x10": brief(c4), "solve_order7_65536x10": brief(s7),
                           "formation_4096x10": brief(c2), "formation_16384x10": brief(big)}
+                if c2_all is not None:
+                    strong["formation_4096x10_all_pairs"] = brief(c2_all)
         for c in (ctx7, ctx9):
             if c is not ctx:
                 c.use_own_stream()

@@ -630,13 +630,14 @@ struct RowSet {
 };
 
 // The exact broad phase of a whole-swarm pass (launch_formation_collide, "cull" path).  Rows and columns are walked in
-// a spatially sorted order (Morton order of the drones' path boxes); every 128-row block and every aligned group of 8
-// columns has the bounding box of its drones' finite samples and the largest of its drones' BOUNDS -- a squared
-// distance each drone is known to attain to some other drone (its sorted neighbours, collide_bound_kernel).  A
-// two-sided block whose box distance exceeds both maxima cannot lower any of its rows' or columns' minima -- nor tie
+// a spatially sorted order (Morton order of the drones' path boxes); every aligned group of 8 drones of that order has
+// the bounding box of its drones' finite samples and the largest of its drones' BOUNDS -- a squared distance each drone
+// is known to attain to some other drone (its sorted neighbours, collide_bound_kernel).  A two-sided share (128 rows x
+// 8 columns) is evaluated unless, for every one of the row block's 16 groups, the box distance to the column group
+// exceeds both groups' largest bounds: then no pair of the share can lower any of its rows' or columns' minima -- nor tie
 // them: the test is strict, and the box distance is formed with the pass's own fma formula, so it never exceeds the
-// squared distance of any pair of the two boxes -- and is skipped.  Minima, partners (compared by ORIGINAL index,
-// `oid`) and hits are those of the full pass.
+// squared distance of any pair of the two boxes.  Minima, partners (compared by ORIGINAL index, `oid`) and hits are
+// those of the full pass, whatever the order and whatever is skipped.
 struct CollideCull {
   const double *colbox;    // [ceil(N / 8)][6] lo x,y,z / hi x,y,z per aligned group of 8 sorted drones
   const double *cmax;      // [ceil(N / 8)] largest bound of the group
@@ -949,12 +950,24 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
 // share k of row block I is the columns 128 I + 8 k .. (+ 8); its first 16 shares are the diagonal block (one-sided
 // among the block's own rows, never culled), the others are two-sided and culled by the box test.
 
-// sample parts per surviving share: enough waves to fill the wave slots once, while a part keeps two chunks
+// Sample parts per surviving share.  A share is kSampleChunk-sample chunks of VALU work (1.7 us of SIMD time each
+// at 8 columns x 128 rows) plus some 1.5 us of its own per item -- list entry, first row loads, the fold; the items are
+// spread over the SIMDs, which run their waves one instruction at a time: the estimate is the number of items a SIMD
+// works off times the length of one, and the part count with the smallest estimate wins (a part keeps two chunks).
 constexpr int kCullMaxParts = 8;
-__device__ __host__ __forceinline__ int cull_sparts(long long tot, int slots, int nch) {
-  int sp = 1;
-  while (sp < kCullMaxParts && tot * sp < slots && nch / (sp * 2) >= 2) sp *= 2;
-  return sp;
+__device__ __host__ __forceinline__ int cull_sparts(int tot, int slots, int nch) {
+  const int simds = slots / 4 > 0 ? slots / 4 : 1;
+  int best = 1;
+  long long best_cost = -1;
+  for (int sp = 1; sp <= kCullMaxParts && (sp == 1 || nch / sp >= 2); ++sp) {
+    const long long serial = ((long long)tot * sp + simds - 1) / simds;
+    const long long cost = serial * (17 * ((nch + sp - 1) / sp) + 15);      // 0.1 us
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = sp;
+    }
+  }
+  return best;
 }
 __device__ __host__ __forceinline__ int cull_nch(int S) {
   const int rem = S % kSampleChunk;
@@ -962,13 +975,23 @@ __device__ __host__ __forceinline__ int cull_nch(int S) {
   return (Sw + kSampleChunk - 1) / kSampleChunk;
 }
 
-// One workgroup per row block: thread k tests share k and the survivors' numbers are written, in order, to
-// surv[I][0 .. cnt[I]).
+// what the broad-phase kernels hand each other (int32 words in device memory)
+enum : int {
+  kMetaStart = 0,      // [n_rb <= 64] first list position of row block I's survivors
+  kMetaTotal = 64,     // survivors (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
+  kMetaParts = 65,     // sample parts per survivor (collide_span_list_kernel, for the merge)
+  kMetaWords = 66
+};
+
+// One workgroup per row block: thread k tests share k (at most 1024 of them: kCullMaxDrones / 8); the survivors are
+// written, in ascending order, to a range of the list that the workgroup reserves with one atomic add -- the row
+// blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
 constexpr int kSelThreads = 1024;
 __global__ void __launch_bounds__(kSelThreads)
-collide_select_kernel(int N, CollideCull cu, int32_t *__restrict__ surv, int maxsh, int32_t *__restrict__ cnt) {
+collide_select_kernel(int N, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt, int32_t *__restrict__ meta) {
   constexpr int GPB = kRowBlock / kColBlock;      // groups of 8 per row block
   __shared__ int wsum[kSelThreads / kWave];
+  __shared__ int sStart;
   __shared__ double sRow[GPB][8];      // the row block's own groups: box, largest bound
   const int I = blockIdx.x, lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
   const int nsh = (N - I * kRowBlock + kColBlock - 1) / kColBlock;
@@ -978,87 +1001,69 @@ collide_select_kernel(int N, CollideCull cu, int32_t *__restrict__ surv, int max
     if (q < ng) sRow[q][k] = k < 6 ? cu.colbox[(size_t)(I * GPB + q) * 6 + k] : cu.cmax[I * GPB + q];
   }
   __syncthreads();
-  int base = 0;
-  for (int k0 = 0; k0 < nsh; k0 += kSelThreads) {
-    const int k = k0 + threadIdx.x;
-    bool keep = false;
-    if (k < nsh) {
-      keep = true;
-      if (k >= GPB) {
-        // Skip the share unless some pair of it could reach (or tie) a minimum of its row or its column: the rows are
-        // taken group by group -- a block of 128 consecutive drones of the sorted order can straddle a jump of the
-        // curve, its groups of 8 hardly ever do.
-        const int J = I * GPB + k;
-        double cb[6];
+  const int k = threadIdx.x;
+  bool keep = false;
+  if (k < nsh) {
+    keep = true;
+    if (k >= GPB) {
+      // Skip the share unless some pair of it could reach (or tie) a minimum of its row or its column: the rows are
+      // taken group by group -- a block of 128 consecutive drones of the sorted order can straddle a jump of the
+      // curve, its groups of 8 hardly ever do.
+      const int J = I * GPB + k;
+      double cb[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) cb[c] = cu.colbox[(size_t)J * 6 + c];
-        const double cm = cu.cmax[J];
-        keep = false;
-        for (int q = 0; q < ng; ++q) {
-          const double lb2 = box_box_lb2(sRow[q], cb);
-          keep |= !((lb2 > sRow[q][6]) & (lb2 > cm));
-        }
+      for (int c = 0; c < 6; ++c) cb[c] = cu.colbox[(size_t)J * 6 + c];
+      const double cm = cu.cmax[J];
+      keep = false;
+      for (int q = 0; q < ng; ++q) {
+        const double lb2 = box_box_lb2(sRow[q], cb);
+        keep |= !((lb2 > sRow[q][6]) & (lb2 > cm));
       }
     }
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) wsum[w] = __popcll(m);
-    __syncthreads();
-    int off = base;
-#pragma unroll
-    for (int q = 0; q < kSelThreads / kWave; ++q) {
-      const int v = wsum[q];
-      off += q < w ? v : 0;
-      base += v;
-    }
-    if (keep) surv[(size_t)I * maxsh + off + __popcll(m & ((1ull << lane) - 1ull))] = k;
-    __syncthreads();
   }
-  if (threadIdx.x == 0) cnt[I] = base;
+  const unsigned long long m = __ballot(keep);
+  if (lane == 0) wsum[w] = __popcll(m);
+  __syncthreads();
+  int off = 0, all = 0;
+#pragma unroll
+  for (int q = 0; q < kSelThreads / kWave; ++q) {
+    const int v = wsum[q];
+    off += q < w ? v : 0;
+    all += v;
+  }
+  if (threadIdx.x == 0) {
+    const int start = atomicAdd(&meta[kMetaTotal], all);
+    sStart = start;
+    meta[kMetaStart + I] = start;
+    cnt[I] = all;
+  }
+  __syncthreads();
+  if (keep) list[sStart + off + __popcll(m & ((1ull << lane) - 1ull))] = (I << 16) | k;
 }
 
-// The surviving shares, walked by a fixed grid of waves: item it = (survivor it / sp, sample part it % sp) in the
-// order of the lists; its row-side partial entry is entry `it` of part_d2 / part_j, the column side goes to the
-// (row block, sample part) slots as in the plain pass.  At most 64 row blocks (kCullMaxDrones): lane I holds the
-// list offset of row block I through LDS.
+// The surviving shares, walked by a fixed grid of waves: item it = (survivor it / sp, sample part it % sp) of the
+// list; its row-side partial entry is entry `it` of part_d2 / part_j, the column side goes to the (row block,
+// sample part) slots as in the plain pass.  The next item's list entry is fetched before the current item runs.
 __global__ void __launch_bounds__(kWave, 4)
 collide_span_list_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
                          double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
-                         int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ surv,
-                         int maxsh, const int32_t *__restrict__ cnt, int sp_force, int slots, int32_t *__restrict__ meta) {
+                         int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
+                         int sp_force, int slots, int32_t *__restrict__ meta) {
   constexpr int CB = kColBlock;
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
-  __shared__ int sPre[kWave];
   const int lane = threadIdx.x;
-  int tot;
-  {
-    const int c = lane < g.n_rb ? cnt[lane] : 0;
-    int inc = c;
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) {
-      const int o = __shfl_up(inc, m);
-      inc += lane >= m ? o : 0;
-    }
-    sPre[lane] = lane < g.n_rb ? inc - c : 0x7fffffff;
-    tot = __builtin_amdgcn_readlane(inc, kWave - 1);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  const int tot = meta[kMetaTotal];
   g.sparts = sp_force > 0 ? sp_force : cull_sparts(tot, slots, cull_nch(g.S));
-  if (blockIdx.x == 0) {      // for the merge: list offsets [0..63], survivors [64], sample parts [65]
-    meta[lane] = sPre[lane];
-    if (lane == 0) {
-      meta[kWave] = tot;
-      meta[kWave + 1] = g.sparts;
-    }
-  }
+  if (blockIdx.x == 0 && lane == 0) meta[kMetaParts] = g.sparts;
   const int items = tot * g.sparts;      // (at most 33280 shares x kCullMaxParts)
-  for (int it = blockIdx.x; it < items; it += gridDim.x) {
+  int it = blockIdx.x;
+  int entry = it < items ? list[it / g.sparts] : 0;
+  while (it < items) {
     const int f = it / g.sparts, h = it - f * g.sparts;
-    const int pre = sPre[lane];
-    const int I = __popcll(__ballot(pre <= f)) - 1;      // the last row block whose list starts at or before f
-    const int k = surv[(size_t)I * maxsh + (f - __builtin_amdgcn_readlane(pre, I))];
+    const int I = entry >> 16, k = entry & 0xffff;
+    const int nxt = it + gridDim.x;
+    entry = nxt < items ? list[nxt / g.sparts] : 0;
     const int cj = I * kRowBlock + k * CB;
     const int ncols = g.Cn - cj < CB ? g.Cn - cj : CB;
     const bool two_sided = k >= kRowBlock / CB;
@@ -1083,6 +1088,7 @@ collide_span_list_kernel(const double *__restrict__ prow_t, const double *__rest
       part_d2[(size_t)it * kRowBlock + rr * kWave + lane] = rs.best[rr];
       part_j[(size_t)it * kRowBlock + rr * kWave + lane] = (rs.best[rr] == INFINITY) ? -1 : rs.bestj[rr];
     }
+    it = nxt;
   }
 }
 
@@ -1169,7 +1175,7 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   if (cnt) {
     // broad-phase pass (collide_span_list_kernel): the row block's surviving shares are consecutive entries
     const int I = __builtin_amdgcn_readfirstlane(r / kRowBlock);      // (kMergeRows divides kRowBlock)
-    const int pre = meta[I], sp = meta[kWave + 1];
+    const int pre = meta[kMetaStart + I], sp = meta[kMetaParts];
     const size_t first = (size_t)pre * sp * kRowBlock + (r - I * kRowBlock);
     sweep(part_d2 + first, part_j + first, kRowBlock, cnt[I] * sp);
     if (I > 0) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * sp);
@@ -1312,8 +1318,10 @@ __device__ __forceinline__ unsigned long long spread3(unsigned long long v) {   
 // without a finite sample get the largest key and sort to the end.
 constexpr int kKeyDrones = 4;
 __global__ void __launch_bounds__(kWave * kKeyDrones)
-collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key) {
+collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key,
+                   int32_t *__restrict__ meta) {
   const int lane = threadIdx.x & (kWave - 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta[kMetaTotal] = 0;      // (the selection adds its survivors)
   const int d = blockIdx.x * kKeyDrones + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   if (d >= N) return;
   const double *p = pos + (size_t)d * S * 3;
@@ -1383,11 +1391,6 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
   int c = 0;
   auto count = [&](int a, int b, auto below) {      // keys [a, b)
     int j = a;
-    // (64 keys per trip: four wide scalar loads in flight -- with one the loop is a chain of their latencies)
-    for (; j + 64 <= b; j += 64) {
-#pragma unroll
-      for (int q = 0; q < 64; ++q) c += below(key[j + q], j + q) ? 1 : 0;
-    }
     for (; j + 16 <= b; j += 16) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) c += below(key[j + q], j + q) ? 1 : 0;
@@ -1607,10 +1610,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   const int E = n_samples * 3;
   if (cull) {
     // Buffers: sorted row image [E][Rp] | sorted columns [N][E] | box [N][6] | colbox [nJ][6] | cmax [nJ] | row-side entries (d2) | column-side slots (d2) || row-side entries (j) |
-    // column-side slots (j, pre-filled -1) | sort keys [N] | perm [N] | surv [n_rb][maxsh] | cnt [n_rb] | meta [66]
+    // column-side slots (j, pre-filled -1) | sort keys [N] | perm [N] | survivor list [shares] | cnt [n_rb] | meta [kMetaWords]
     const int N = n_rows;
     const size_t nJ = ((size_t)N + kColBlock - 1) / kColBlock;
-    const int maxsh = (int)nJ;
     long long shares = 0;
     for (int I = 0; I < g.n_rb; ++I) shares += (N - I * kRowBlock + kColBlock - 1) / kColBlock;
     const int spmax = kCullMaxParts;
@@ -1622,7 +1624,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     const size_t centries = (size_t)g.n_rb * spmax * N;
     const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries;
     const size_t ints = entries + centries + (size_t)N /* sort keys */ + (size_t)N +
-                        (size_t)g.n_rb * maxsh + g.n_rb + kWave + 2;
+                        (size_t)shares + g.n_rb + kMetaWords;
     int rc = ensure(ctx, ctx->stage[7], doubles * sizeof(double) + ints * sizeof(int32_t) + 64);
     if (rc) return rc;
     double *rows_t = (double *)ctx->stage[7].p;
@@ -1631,10 +1633,10 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     double *pd = cmax + nJ, *cd = pd + entries;
     int32_t *pj = (int32_t *)(cd + centries), *ci = pj + entries;
     unsigned *key = (unsigned *)(ci + centries);
-    int32_t *perm = (int32_t *)(key + N), *surv = perm + N, *cnt = surv + (size_t)g.n_rb * maxsh, *meta = cnt + g.n_rb;
+    int32_t *perm = (int32_t *)(key + N), *surv = perm + N, *cnt = surv + shares, *meta = cnt + g.n_rb;
     ctx->collide_meta = meta;
     hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
-                       ctx->stream, pos_cols, N, n_samples, box, key);
+                       ctx->stream, pos_cols, N, n_samples, box, key, meta);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_rank_kernel, dim3((N + kWave - 1) / kWave), dim3(kWave * kRankWaves), 0, ctx->stream,
                        (const unsigned *)key, N, perm);
@@ -1648,12 +1650,12 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                        colbox, cmax);
     MSNAP_HIP(ctx, hipGetLastError());
     CollideCull cu{colbox, cmax};
-    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb), dim3(kSelThreads), 0, ctx->stream, N, cu, surv, maxsh, cnt);
+    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb), dim3(kSelThreads), 0, ctx->stream, N, cu, surv, cnt, meta);
     MSNAP_HIP(ctx, hipGetLastError());
     const long long grid = shares * spmax < slots ? shares * spmax : slots;
     hipLaunchKernelGGL(collide_span_list_kernel, dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
-                       (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, maxsh,
-                       (const int32_t *)cnt, sp_force, (int)slots, meta);
+                       (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, sp_force,
+                       (int)slots, meta);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                        ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)perm,

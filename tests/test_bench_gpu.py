@@ -43,7 +43,9 @@ def test_bench_line_contract():
     assert cfg["2"]["solve_failures"] == cfg["3"]["solve_failures"] == cfg["4"]["solve_failures"] == 0
     assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-6
     assert set(cfg["3"]["stage_us"]) == {"solve", "sample", "pairwise", "mesh"}
-    assert 0.0 < cfg["2"]["stages"]["pairwise"]["frac"] < 1.0
+    pw = cfg["2"]["stages"]["pairwise"]
+    assert 0.0 < pw["frac"] < 1.0 and pw["frac_on_all_pairs"] >= pw["frac"]
+    assert pw["broad_phase"] is not None and 0 < pw["broad_phase"]["shares_evaluated"] <= pw["broad_phase"]["shares"]
     assert cfg["2"]["stages"]["pairwise"]["pairs_evaluated_once_over_all_ranks"] is True
     assert cfg["4"]["stages"]["solve"]["kernel"] == "msnap::solve_kernel_twin<5, 10>"      # what the library says it launched
     assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-9
