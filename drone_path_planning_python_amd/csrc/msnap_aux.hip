@@ -662,7 +662,7 @@ __device__ __forceinline__ double box_box_lb2(const double *__restrict__ a, cons
 template <int NC, bool CULL = false>
 __device__ __forceinline__ void collide_block(const CollideGeom &g, const double *__restrict__ prowT,
                                               const double *__restrict__ pcol, int cj, int ncols, bool two_sided,
-                                              RowSet &rs, int I, int h, int lane, double *sFold, int *sFoldI,
+                                              RowSet &rs, int I, int h, int crow, int lane, double *sFold, int *sFoldI,
                                               double *__restrict__ cpart_d2, int32_t *__restrict__ cpart_i,
                                               const int32_t *__restrict__ oid = nullptr) {
 #pragma clang fp contract(off)
@@ -825,7 +825,7 @@ __device__ __forceinline__ void collide_block(const CollideGeom &g, const double
       ci = take ? oi : ci;
     }
     if (part == 0 && c < ncols) {
-      const size_t slot = ((size_t)(I - g.I_lo) * g.sparts + h) * g.R + (size_t)(cj + c - g.os);
+      const size_t slot = (size_t)crow * g.R + (size_t)(cj + c - g.os);      // crow: the (row block, sample part) slot row
       cpart_d2[slot] = cm;
       cpart_i[slot] = (cm == INFINITY) ? -1 : (CULL ? ci : g.ro + I * kRowBlock + ci);
     }
@@ -905,6 +905,7 @@ __device__ __forceinline__ void collide_span_body(const double *__restrict__ pro
       rs.bestj[rr] = -1;
     }
     const double *prowT = prow_t + (size_t)(I - g.I_lo) * kRowBlock;
+    const int crow = (I - g.I_lo) * g.sparts + h;
     for (int ux = ua; ux < ue;) {
       // a block: up to CB consecutive columns that do not straddle a boundary of the line
       const int cj = (g.sym && ux >= g.os) ? ux + skip : ux;
@@ -921,11 +922,11 @@ __device__ __forceinline__ void collide_span_body(const double *__restrict__ pro
       const int ncols = lim < CB ? lim : CB;
       ux += ncols;
       if (ncols <= 2)
-        collide_block<2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else if (ncols <= kColBlock / 2)
-        collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<kColBlock / 2>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i);
       else
-        collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i);
+        collide_block<kColBlock>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i);
     }
     // one partial entry per (wave, row block): w + I is unique (a later wave starts in a later or the same
     // row block) and the entries of row block I are the contiguous ids of the waves that meet it
@@ -954,8 +955,23 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
 // at 8 columns x 128 rows) plus some 1.5 us of its own per item -- list entry, first row loads, the fold; the items are
 // spread over the SIMDs, which run their waves one instruction at a time: the estimate is the number of items a SIMD
 // works off times the length of one, and the part count with the smallest estimate wins (a part keeps two chunks).
+// The fixture's 1393 survivors take 95-96 us per pass with 2, 3 or 4 parts alike (1: 106); cutting some shares into one
+// part more than the others so that the items are exactly the wave slots changed nothing there and cost a sparse
+// swarm 10 us (its uncut shares become the long poles) -- CullSplit keeps that form, x = 0.
 constexpr int kCullMaxParts = 8;
-__device__ __host__ __forceinline__ int cull_sparts(int tot, int slots, int nch) {
+struct CullSplit {
+  int lo, hi, x;      // x shares in `hi` parts, the others in `lo`
+  __device__ __host__ __forceinline__ int items(int tot) const { return x * hi + (tot - x) * lo; }
+  // first item of list position f
+  __device__ __host__ __forceinline__ int item_of(int f) const { return f <= x ? f * hi : x * hi + (f - x) * lo; }
+};
+__device__ __host__ __forceinline__ CullSplit cull_split(int tot, int slots, int nch, int force) {
+  CullSplit c;
+  c.x = 0;
+  if (force > 0) {
+    c.lo = c.hi = force < kCullMaxParts ? force : kCullMaxParts;
+    return c;
+  }
   const int simds = slots / 4 > 0 ? slots / 4 : 1;
   int best = 1;
   long long best_cost = -1;
@@ -967,7 +983,8 @@ __device__ __host__ __forceinline__ int cull_sparts(int tot, int slots, int nch)
       best = sp;
     }
   }
-  return best;
+  c.lo = c.hi = best;
+  return c;
 }
 __device__ __host__ __forceinline__ int cull_nch(int S) {
   const int rem = S % kSampleChunk;
@@ -979,8 +996,8 @@ __device__ __host__ __forceinline__ int cull_nch(int S) {
 enum : int {
   kMetaStart = 0,      // [n_rb <= 64] first list position of row block I's survivors
   kMetaTotal = 64,     // survivors (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
-  kMetaParts = 65,     // sample parts per survivor (collide_span_list_kernel, for the merge)
-  kMetaWords = 66
+  kMetaParts = 65,     // CullSplit lo, hi, x (collide_span_list_kernel, for the merge)
+  kMetaWords = 68
 };
 
 // One workgroup per row block: thread k tests share k (at most 1024 of them: kCullMaxDrones / 8); the survivors are
@@ -1054,16 +1071,25 @@ collide_span_list_kernel(const double *__restrict__ prow_t, const double *__rest
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
   const int tot = meta[kMetaTotal];
-  g.sparts = sp_force > 0 ? sp_force : cull_sparts(tot, slots, cull_nch(g.S));
-  if (blockIdx.x == 0 && lane == 0) meta[kMetaParts] = g.sparts;
-  const int items = tot * g.sparts;      // (at most 33280 shares x kCullMaxParts)
+  const CullSplit sp = cull_split(tot, slots, cull_nch(g.S), sp_force);
+  if (blockIdx.x == 0 && lane == 0) {
+    meta[kMetaParts] = sp.lo;
+    meta[kMetaParts + 1] = sp.hi;
+    meta[kMetaParts + 2] = sp.x;
+  }
+  const int items = sp.items(tot);      // (at most 33280 shares x kCullMaxParts)
+  const int xi = sp.x * sp.hi;          // items of the shares cut into `hi` parts
+  auto share_of = [&](int it) { return it < xi ? it / sp.hi : sp.x + (it - xi) / sp.lo; };
   int it = blockIdx.x;
-  int entry = it < items ? list[it / g.sparts] : 0;
+  int entry = it < items ? list[share_of(it)] : 0;
   while (it < items) {
-    const int f = it / g.sparts, h = it - f * g.sparts;
+    const int f = share_of(it);
+    g.sparts = it < xi ? sp.hi : sp.lo;
+    const int h = it - sp.item_of(f);
     const int I = entry >> 16, k = entry & 0xffff;
     const int nxt = it + gridDim.x;
-    entry = nxt < items ? list[nxt / g.sparts] : 0;
+    entry = nxt < items ? list[share_of(nxt)] : 0;
+    const int crow = I * sp.hi + h;      // column-side slot row: `hi` rows per row block
     const int cj = I * kRowBlock + k * CB;
     const int ncols = g.Cn - cj < CB ? g.Cn - cj : CB;
     const bool two_sided = k >= kRowBlock / CB;
@@ -1078,11 +1104,11 @@ collide_span_list_kernel(const double *__restrict__ prow_t, const double *__rest
     }
     const double *prowT = prow_t + (size_t)I * kRowBlock;
     if (ncols <= 2)
-      collide_block<2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+      collide_block<2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
     else if (ncols <= CB / 2)
-      collide_block<CB / 2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+      collide_block<CB / 2, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
     else
-      collide_block<CB, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
+      collide_block<CB, true>(g, prowT, pcol, cj, ncols, two_sided, rs, I, h, crow, lane, sFold, sFoldI, cpart_d2, cpart_i, oid);
 #pragma unroll
     for (int rr = 0; rr < kRowsPerLane; ++rr) {
       part_d2[(size_t)it * kRowBlock + rr * kWave + lane] = rs.best[rr];
@@ -1149,6 +1175,7 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
   const int r_raw = blockIdx.x * kMergeRows + lr;
   const int r = r_raw < g.R ? r_raw : g.R - 1;
+  const int out = oid ? oid[r] : r;      // cull path: row r of the sorted pass is drone oid[r] (fetched under the sweeps)
   double best = INFINITY;
   int bj = -1;
   constexpr int U = 8;      // entries fetched per round: the loads of a round are independent
@@ -1175,10 +1202,14 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
   if (cnt) {
     // broad-phase pass (collide_span_list_kernel): the row block's surviving shares are consecutive entries
     const int I = __builtin_amdgcn_readfirstlane(r / kRowBlock);      // (kMergeRows divides kRowBlock)
-    const int pre = meta[kMetaStart + I], sp = meta[kMetaParts];
-    const size_t first = (size_t)pre * sp * kRowBlock + (r - I * kRowBlock);
-    sweep(part_d2 + first, part_j + first, kRowBlock, cnt[I] * sp);
-    if (I > 0) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * sp);
+    CullSplit sp;
+    sp.lo = meta[kMetaParts];
+    sp.hi = meta[kMetaParts + 1];
+    sp.x = meta[kMetaParts + 2];
+    const int f0 = meta[kMetaStart + I], first_item = sp.item_of(f0), n_items = sp.item_of(f0 + cnt[I]) - first_item;
+    const size_t first = (size_t)first_item * kRowBlock + (r - I * kRowBlock);
+    sweep(part_d2 + first, part_j + first, kRowBlock, n_items);
+    if (I > 0) sweep(cpart_d2 + r, cpart_i + r, (size_t)g.R, I * sp.hi);
   } else if (g.total > 0) {
     // row side: the shares of this launch that met this drone's row block
     const int I = r / kRowBlock;
@@ -1212,7 +1243,6 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
       min_dist[r] = best;
       partner[r] = bj;
     } else {
-      const int out = oid ? oid[r] : r;      // cull path: row r of the sorted pass is drone oid[r]
       const double dist = sqrt(best);
       min_dist[out] = dist;
       partner[out] = bj;
@@ -1371,44 +1401,45 @@ collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restr
 }
 
 // The sort, as a rank count spread over the chip: drones are ordered by (key, index) -- all distinct -- so the sorted
-// position of drone i is the number of drones below it.  One workgroup of 16 wavefronts per 64 drones: wavefront w
-// counts over the w-th sixteenth of the keys (wave-uniform: scalar loads, one 32-bit compare and one add-with-carry
-// per key: "key_j <= key_i" for the drones before the wavefront's own 64, "<" behind them, the pair compare among
-// them), the sixteen counts are added through LDS.  N^2 compares -- 17 M at 4096 drones, a few us over 64 CUs --
-// against the 78 dependent stages of a sorting network on one CU (36 us measured).
+// position of drone i is the number of drones below it.  One workgroup of 16 wavefronts per 16 drones: the lanes hold
+// the (key << 32 | index) words of ALL drones in registers (wavefront w the w-th sixteenth, up to 8 per lane), the 16
+// drones of the tile are wave-uniform: one 64-bit compare per 64 pairs, the count is the population of its lane mask
+// (scalar unit), the sixteen wavefronts' counts are added through LDS.  N^2 / 64 vector compares -- 260 k at 4096
+// drones -- over 256 workgroups; counting in the lanes (a compare and an add-with-carry per pair, 64 drones per
+// workgroup) took 8-10 us, a 78-stage bitonic network in one workgroup 36 us.
 // perm[sorted position] = original index.
 constexpr int kCullMaxDrones = 8192;
 constexpr int kCullMinDrones = 3072;
 constexpr int kRankWaves = 16;
+constexpr int kRankTile = 16;
+constexpr int kRankKeys = kCullMaxDrones / (kRankWaves * kWave);      // words per lane at most
 __global__ void __launch_bounds__(kWave * kRankWaves)
 collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict__ perm) {
-  __shared__ int cnt[kRankWaves][kWave];
+  __shared__ int cnt[kRankWaves][kRankTile];
   const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int i0 = blockIdx.x * kWave, i = i0 + lane;
-  const unsigned ki = i < N ? key[i] : 0xffffffffu;
-  const int per = ((N + kRankWaves - 1) / kRankWaves + 15) & ~15;
-  const int j0 = w * per < N ? w * per : N, j1 = (j0 + per < N) ? j0 + per : N;
-  int c = 0;
-  auto count = [&](int a, int b, auto below) {      // keys [a, b)
-    int j = a;
-    for (; j + 16 <= b; j += 16) {
+  const int nq = (N + kRankWaves * kWave - 1) / (kRankWaves * kWave);      // words per lane
+  unsigned long long mine[kRankKeys];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) c += below(key[j + q], j + q) ? 1 : 0;
-    }
-    for (; j < b; ++j) c += below(key[j], j) ? 1 : 0;
-  };
-  const int ia = i0 < j1 ? (i0 > j0 ? i0 : j0) : j1;                     // [j0, ia): before the tile
-  const int ib = i0 + kWave < j1 ? (i0 + kWave > ia ? i0 + kWave : ia) : j1;   // [ia, ib): inside it
-  count(j0, ia, [&](unsigned kj, int) { return kj <= ki; });
-  count(ia, ib, [&](unsigned kj, int j) { return kj < ki || (kj == ki && j < i); });
-  count(ib, j1, [&](unsigned kj, int) { return kj < ki; });
-  cnt[w][lane] = c;
+  for (int q = 0; q < kRankKeys; ++q) {
+    const int j = (w * nq + q) * kWave + lane;
+    mine[q] = (q < nq && j < N) ? ((unsigned long long)key[j] << 32) | (unsigned)j : ~0ull;      // (~0: below nothing)
+  }
+  const int i0 = blockIdx.x * kRankTile;
+#pragma unroll
+  for (int t = 0; t < kRankTile; ++t) {
+    const int i = i0 + t < N ? i0 + t : N - 1;      // wave-uniform
+    const unsigned long long ki = ((unsigned long long)key[i] << 32) | (unsigned)i;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < kRankKeys; ++q) c += __popcll(__ballot(mine[q] < ki));
+    if (lane == 0) cnt[w][t] = c;
+  }
   __syncthreads();
-  if (w == 0 && i < N) {
+  if (threadIdx.x < kRankTile && i0 + (int)threadIdx.x < N) {
     int r = 0;
 #pragma unroll
-    for (int q = 0; q < kRankWaves; ++q) r += cnt[q][lane];
-    perm[r] = i;
+    for (int q = 0; q < kRankWaves; ++q) r += cnt[q][threadIdx.x];
+    perm[r] = i0 + threadIdx.x;
   }
 }
 
@@ -1618,8 +1649,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     const int spmax = kCullMaxParts;
     ctx->collide_last_shares = (int)shares;
     const int sp_force = ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0;
-    // row-side entries: one per item; cull_sparts doubles the parts only while the items do not fill the slots
-    const long long items_max = sp_force ? shares * sp_force : (shares > 2 * slots ? shares : 2 * slots);
+    // row-side entries: one per item; cull_split cuts shares only to fill the wave slots once
+    const long long items_max = sp_force ? shares * sp_force : (shares > slots ? shares : slots);
     const size_t entries = (size_t)items_max * kRowBlock;
     const size_t centries = (size_t)g.n_rb * spmax * N;
     const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries;
@@ -1638,7 +1669,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
                        ctx->stream, pos_cols, N, n_samples, box, key, meta);
     MSNAP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(collide_rank_kernel, dim3((N + kWave - 1) / kWave), dim3(kWave * kRankWaves), 0, ctx->stream,
+    hipLaunchKernelGGL(collide_rank_kernel, dim3((N + kRankTile - 1) / kRankTile), dim3(kWave * kRankWaves), 0, ctx->stream,
                        (const unsigned *)key, N, perm);
     MSNAP_HIP(ctx, hipGetLastError());
     const int ny = (E + 31) / 32;
