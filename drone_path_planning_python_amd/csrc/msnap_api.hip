@@ -54,7 +54,7 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"collide_cull_mode", "MSNAP_COLLIDE_CULL_MODE"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
 };
 
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
@@ -76,6 +76,7 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "collide_no_sym")) return &ctx->collide_no_sym;
   if (!strcmp(name, "collide_no_cull")) return &ctx->collide_no_cull;
   if (!strcmp(name, "collide_cull_min_drones")) return &ctx->collide_cull_min_drones;
+  if (!strcmp(name, "collide_cull_mode")) return &ctx->collide_cull_mode;
   if (!strcmp(name, "collide_last_cull")) return &ctx->collide_last_cull;
   if (!strcmp(name, "collide_last_shares")) return &ctx->collide_last_shares;
   if (!strcmp(name, "collide_last_sym")) return &ctx->collide_last_sym;   // (read: what the last pass did)
@@ -240,6 +241,16 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
         return MSNAP_EHIP;
     }
     *value = (long)n;
+    return MSNAP_OK;
+  }
+  if (!strcmp(name, "collide_last_group_pairs")) {   // surviving group pairs of the last broad-phase pass (synchronises)
+    int32_t n = 0;
+    if (ctx->collide_last_cull && ctx->collide_meta) {
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+          hipMemcpy(&n, ctx->collide_meta + 68, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+        return MSNAP_EHIP;
+    }
+    *value = n;
     return MSNAP_OK;
   }
   if (!strcmp(name, "collide_last_survivors")) {   // of the last broad-phase pass (synchronises the stream)

@@ -995,17 +995,79 @@ __device__ __host__ __forceinline__ int cull_nch(int S) {
 // what the broad-phase kernels hand each other (int32 words in device memory)
 enum : int {
   kMetaStart = 0,      // [n_rb <= 64] first list position of row block I's survivors
-  kMetaTotal = 64,     // survivors (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
+  kMetaTotal = 64,     // surviving shares (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
   kMetaParts = 65,     // CullSplit lo, hi, x (collide_span_list_kernel, for the merge)
-  kMetaWords = 68
+  kMetaGroups = 68,    // surviving GROUP PAIRS (zeroed and reserved like kMetaTotal)
+  kMetaWords = 70
 };
+
+// The second granularity of the broad phase: pairs of GROUPS (8 x 8 drones of the sorted order).  Of a surviving share
+// (128 rows x 8 columns) usually one or two of its 16 row groups are what kept it; the group pairs that pass the same
+// test are a few per cent of all (fixture: 3919 of 131 328, 0.25 M pairs against the surviving shares' 1.43 M).  They
+// are evaluated by collide_group_kernel with the samples across the lanes; the minima meet in per-drone atomics.
+struct CullGroups {
+  int32_t *glist;                 // [cap] (a << 16 | b), a <= b: surviving group pairs, any order
+  unsigned long long *dmin;       // [N] bit pattern of the smallest squared distance so far (sorted index)
+  int32_t *pmin;                  // [N] lowest ORIGINAL partner index attaining it (collide_resolve_kernel)
+  double *cand_d2;                // [cap][16] what item `it` found for its 8 row drones and its 8 column drones
+  int32_t *cand_j;
+  int cap;                        // list capacity: more surviving group pairs than this take the share path
+  int mode;                       // 0: choose per pass (cull_use_groups), 1: shares, 2: groups (if they fit)
+};
+// Same arithmetic per pair and sample on both paths; the group kernel spends about 2.2 x as many vector instructions per
+// pair-sample (91 samples on 128 lanes, the cross-lane folds), the share kernel runs a single short round at 0.7 of its
+// pace: groups when 64 x 2.2 x (group pairs) < 1024 x 1.45 x (shares).
+__device__ __host__ __forceinline__ bool cull_use_groups(int shares, int groups, const CullGroups &cg) {
+  if (cg.mode == 1 || groups > cg.cap) return false;
+  if (cg.mode == 2) return true;
+  return (long long)groups * 141 < (long long)shares * 1485;
+}
 
 // One workgroup per row block: thread k tests share k (at most 1024 of them: kCullMaxDrones / 8); the survivors are
 // written, in ascending order, to a range of the list that the workgroup reserves with one atomic add -- the row
 // blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
 constexpr int kSelThreads = 1024;
 __global__ void __launch_bounds__(kSelThreads)
-collide_select_kernel(int N, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt, int32_t *__restrict__ meta) {
+collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt,
+                      int32_t *__restrict__ meta, CullGroups cg) {
+  if ((int)blockIdx.x >= n_rb) {
+    // group pairs (a, b), a <= b: workgroup a tests every b (the same strict test on the two groups' boxes and bounds);
+    // the survivors of a workgroup are appended with one atomic reservation, the workgroups in no particular order
+    __shared__ double sA[8];
+    const int a = blockIdx.x - n_rb, nG = (N + kColBlock - 1) / kColBlock, lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x < 7) sA[threadIdx.x] = threadIdx.x < 6 ? cu.colbox[(size_t)a * 6 + threadIdx.x] : cu.cmax[a];
+    __syncthreads();
+    __shared__ int gsum[kSelThreads / kWave];
+    __shared__ int gbase;
+    const int w = threadIdx.x / kWave;
+    for (int b0 = a; b0 < nG; b0 += kSelThreads) {
+      const int b = b0 + threadIdx.x;
+      bool keep = false;
+      if (b < nG) {
+        keep = b == a;
+        if (!keep) {
+          const double lb2 = box_box_lb2(sA, cu.colbox + (size_t)b * 6);
+          keep = !((lb2 > sA[6]) & (lb2 > cu.cmax[b]));
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) gsum[w] = __popcll(m);
+      __syncthreads();
+      int off = 0, all = 0;
+#pragma unroll
+      for (int q = 0; q < kSelThreads / kWave; ++q) {
+        const int v = gsum[q];
+        off += q < w ? v : 0;
+        all += v;
+      }
+      if (threadIdx.x == 0) gbase = atomicAdd(&meta[kMetaGroups], all);      // one reservation per workgroup and trip
+      __syncthreads();
+      const int pos = gbase + off + __popcll(m & ((1ull << lane) - 1ull));
+      if (keep && pos < cg.cap) cg.glist[pos] = (a << 16) | b;
+      __syncthreads();
+    }
+    return;
+  }
   constexpr int GPB = kRowBlock / kColBlock;      // groups of 8 per row block
   __shared__ int wsum[kSelThreads / kWave];
   __shared__ int sStart;
@@ -1065,12 +1127,13 @@ __global__ void __launch_bounds__(kWave, 4)
 collide_span_list_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
                          double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
                          int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
-                         int sp_force, int slots, int32_t *__restrict__ meta) {
+                         int sp_force, int slots, int32_t *__restrict__ meta, CullGroups cg) {
   constexpr int CB = kColBlock;
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
   const int tot = meta[kMetaTotal];
+  if (cull_use_groups(tot, meta[kMetaGroups], cg)) return;      // this pass is evaluated group pair by group pair
   const CullSplit sp = cull_split(tot, slots, cull_nch(g.S), sp_force);
   if (blockIdx.x == 0 && lane == 0) {
     meta[kMetaParts] = sp.lo;
@@ -1115,6 +1178,133 @@ collide_span_list_kernel(const double *__restrict__ prow_t, const double *__rest
       part_j[(size_t)it * kRowBlock + rr * kWave + lane] = (rs.best[rr] == INFINITY) ? -1 : rs.bestj[rr];
     }
     it = nxt;
+  }
+}
+
+// One wavefront per surviving group pair (a, b): 32 SAMPLES x the two halves of the column group across the lanes
+// (lane = 32 half + sample; three trips for 65..96 samples), the 8 rows x 4 columns of the half in registers -- both
+// drones' positions come as coalesced loads of the sorted drone-major copy, no scalar or LDS operand traffic.  After the
+// samples a reduce-scatter butterfly inside each half (32 -> 16 -> ... -> 1 value per lane, halving the lane span each
+// time) leaves pair (r, c) = ((lane >> 2) & 7, lane & 3) of the half in its lane; row-side (over c, then over the halves)
+// and column-side (over r) candidates follow with lexicographic (distance, ORIGINAL index) folds.  Each candidate goes
+// to the item's slot and, as a bit pattern (squared distances are non-negative doubles: ordered like their patterns),
+// into an atomic minimum per drone; collide_resolve_kernel then lets the candidates that equal their drone's minimum bid
+// for the lowest partner.
+constexpr int kGroupHalf = kColBlock / 2;
+constexpr int kGroupCap = 1 << 18;      // group pairs the list holds (all 131 328 of 4096 drones; 8192 have 524 800)
+constexpr int kGroupLanes = kWave / 2;  // samples per trip
+__global__ void __launch_bounds__(kWave, 3)
+collide_group_kernel(const double *__restrict__ pcol, int N, int S, const int32_t *__restrict__ oid,
+                     const int32_t *__restrict__ meta, CullGroups cg) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x;
+  const int tot = meta[kMetaGroups];
+  if (!cull_use_groups(meta[kMetaTotal], tot, cg)) return;
+  const unsigned stride = (unsigned)S * 3u;
+  const int half = lane >> 5, ls = lane & (kGroupLanes - 1);
+  // this lane's pair after the butterfly
+  const int pr = ls >> 2, pc = ls & (kGroupHalf - 1);
+  for (int it = blockIdx.x; it < tot; it += gridDim.x) {
+    const int entry = cg.glist[it];
+    const int a = entry >> 16, b = entry & 0xffff;
+    const bool diag = a == b;
+    double acc[kColBlock * kGroupHalf];
+#pragma unroll
+    for (int p = 0; p < kColBlock * kGroupHalf; ++p) acc[p] = INFINITY;
+#pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += kGroupLanes) {
+      const int sq = s0 + ls < S ? s0 + ls : S - 1;      // (a sample seen twice does not change a minimum)
+      const unsigned off = (unsigned)sq * 3u;
+      double cx[kGroupHalf], cy[kGroupHalf], cz[kGroupHalf];
+#pragma unroll
+      for (int c = 0; c < kGroupHalf; ++c) {
+        const int d = b * kColBlock + half * kGroupHalf + c;      // (a last group may be short: clamped, masked below)
+        const double *p = pcol + (size_t)(d < N ? d : N - 1) * stride;
+        cx[c] = p[off];
+        cy[c] = p[off + 1];
+        cz[c] = p[off + 2];
+      }
+#pragma unroll
+      for (int r = 0; r < kColBlock; ++r) {
+        const int d = a * kColBlock + r;
+        const double *p = pcol + (size_t)(d < N ? d : N - 1) * stride;
+        const double x = p[off], y = p[off + 1], z = p[off + 2];
+#pragma unroll
+        for (int c = 0; c < kGroupHalf; ++c) {
+          const double dx = cx[c] - x, dy = cy[c] - y, dz = cz[c] - z;
+          acc[r * kGroupHalf + c] = __builtin_fmin(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), acc[r * kGroupHalf + c]);
+        }
+      }
+    }
+    // reduce-scatter over the 32 lanes of the half: 32 values per lane -> 1, pair p = lane & 31
+#pragma unroll
+    for (int n = 16, m = 16; n >= 1; n >>= 1, m >>= 1) {
+      const bool up = (lane & m) != 0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const double keep = up ? acc[i + n] : acc[i], send = up ? acc[i] : acc[i + n];
+        acc[i] = __builtin_fmin(keep, __shfl_xor(send, m));
+      }
+    }
+    double v = acc[0];
+    const int ra = a * kColBlock + pr, cb = b * kColBlock + half * kGroupHalf + pc;
+    const int oi = oid[ra < N ? ra : N - 1], oj = oid[cb < N ? cb : N - 1];
+    if (ra >= N || cb >= N || (diag && ra == cb)) v = INFINITY;
+    // row side: over the 4 columns of the half (lane bits 0, 1), then over the halves (bit 5)
+    {
+      double w = v;
+      int wj = oj;
+#pragma unroll
+      for (int m = 1; m <= 32; m = (m == 2 ? 32 : m << 1)) {
+        const double o = __shfl_xor(w, m);
+        const int ojx = __shfl_xor(wj, m);
+        const bool take = (o < w) | ((o == w) & (ojx < wj));
+        w = take ? o : w;
+        wj = take ? ojx : wj;
+      }
+      if ((lane & 35) == 0) {      // half 0, pc == 0: lane = 4 pr
+        const bool have = w < INFINITY;
+        cg.cand_d2[(size_t)it * 16 + pr] = w;
+        cg.cand_j[(size_t)it * 16 + pr] = have ? wj : -1;
+        if (have) atomicMin(&cg.dmin[ra], (unsigned long long)__double_as_longlong(w));
+      }
+    }
+    // column side: over the 8 rows (lane bits 2..4); the diagonal group's columns are its rows
+    {
+      double w = v;
+      int wi = oi;
+#pragma unroll
+      for (int m = 4; m <= 16; m <<= 1) {
+        const double o = __shfl_xor(w, m);
+        const int oix = __shfl_xor(wi, m);
+        const bool take = (o < w) | ((o == w) & (oix < wi));
+        w = take ? o : w;
+        wi = take ? oix : wi;
+      }
+      if (ls < kGroupHalf) {      // pr == 0: lane = 32 half + pc
+        const int k = kColBlock + half * kGroupHalf + pc;
+        const bool have = !diag && w < INFINITY;
+        cg.cand_d2[(size_t)it * 16 + k] = w;
+        cg.cand_j[(size_t)it * 16 + k] = have ? wi : -1;
+        if (have) atomicMin(&cg.dmin[cb], (unsigned long long)__double_as_longlong(w));
+      }
+    }
+  }
+}
+
+// Every candidate that equals its drone's minimum bids for the partner: the lowest ORIGINAL index wins, as in the
+// all-pairs pass (ties between equidistant neighbours).
+__global__ void __launch_bounds__(256)
+collide_resolve_kernel(int N, const int32_t *__restrict__ meta, CullGroups cg) {
+  const int tot = meta[kMetaGroups];
+  if (!cull_use_groups(meta[kMetaTotal], tot, cg)) return;
+  const long long n = (long long)tot * 16;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int j = cg.cand_j[i];
+    if (j < 0) continue;
+    const int entry = cg.glist[i >> 4], k = (int)(i & 15);
+    const int d = k < kColBlock ? (entry >> 16) * kColBlock + k : (entry & 0xffff) * kColBlock + (k - kColBlock);
+    if ((unsigned long long)__double_as_longlong(cg.cand_d2[i]) == cg.dmin[d]) atomicMin(&cg.pmin[d], j);
   }
 }
 
@@ -1169,7 +1359,23 @@ __global__ void __launch_bounds__(kMergeRows * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
                      double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit,
-                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta) {
+                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta,
+                     CullGroups cg) {
+  if (cnt && cull_use_groups(meta[kMetaTotal], meta[kMetaGroups], cg)) {
+    // the pass was evaluated group pair by group pair: the per-drone atomics hold the result
+    if (threadIdx.x < kMergeRows) {
+      const int r = blockIdx.x * kMergeRows + threadIdx.x;
+      if (r < g.R) {
+        const double best = __longlong_as_double((long long)cg.dmin[r]);
+        const int out = oid[r];
+        const double dist = sqrt(best);
+        min_dist[out] = dist;
+        partner[out] = best < INFINITY ? cg.pmin[r] : -1;
+        hit[out] = (dist < 2.0 * radius) ? 1 : 0;
+      }
+    }
+    return;
+  }
   __shared__ double sD[kMergeParts][kMergeRows];
   __shared__ int sJ[kMergeParts][kMergeRows];
   const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
@@ -1351,7 +1557,10 @@ __global__ void __launch_bounds__(kWave * kKeyDrones)
 collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key,
                    int32_t *__restrict__ meta) {
   const int lane = threadIdx.x & (kWave - 1);
-  if (blockIdx.x == 0 && threadIdx.x == 0) meta[kMetaTotal] = 0;      // (the selection adds its survivors)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {      // (the selection adds its survivors)
+    meta[kMetaTotal] = 0;
+    meta[kMetaGroups] = 0;
+  }
   const int d = blockIdx.x * kKeyDrones + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   if (d >= N) return;
   const double *p = pos + (size_t)d * S * 3;
@@ -1457,7 +1666,8 @@ constexpr int kBoundGroups = 16;
 constexpr int kBoundReach = 4;
 __global__ void __launch_bounds__(kBoundRows * kBoundGroups)
 collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, const double *__restrict__ box,
-                     const int32_t *__restrict__ perm, double *__restrict__ colbox, double *__restrict__ cmax) {
+                     const int32_t *__restrict__ perm, double *__restrict__ colbox, double *__restrict__ cmax,
+                     unsigned long long *__restrict__ dmin, int32_t *__restrict__ pmin) {
 #pragma clang fp contract(off)
   static_assert(kBoundRows == kWave, "a sample group is one wavefront");
   __shared__ double sf[kBoundReach][kBoundGroups][kBoundRows];
@@ -1469,6 +1679,10 @@ collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, co
   // the drone's box, for the last step: fetched first, it arrives under the sample loads
   double g8[7];
   if (sg == 0) {
+    if (live) {      // the per-drone atomics of the group-pair path (CullGroups)
+      dmin[r] = 0x7ff0000000000000ull;      // +inf
+      pmin[r] = 0x7fffffff;
+    }
     const int o = perm[rc];
 #pragma unroll
     for (int k = 0; k < 6; ++k) g8[k] = box[(size_t)o * 6 + k];
@@ -1566,7 +1780,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
                        (const int32_t *)nullptr, radius, min_dist, partner, hit, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
@@ -1653,18 +1867,26 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     const long long items_max = sp_force ? shares * sp_force : (shares > slots ? shares : slots);
     const size_t entries = (size_t)items_max * kRowBlock;
     const size_t centries = (size_t)g.n_rb * spmax * N;
-    const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries;
-    const size_t ints = entries + centries + (size_t)N /* sort keys */ + (size_t)N +
-                        (size_t)shares + g.n_rb + kMetaWords;
+    // group-pair path (CullGroups): list, candidate slots (16 per item), per-drone atomics
+    const long long all_groups = (long long)nJ * (nJ + 1) / 2;
+    const int gcap = (int)(all_groups < kGroupCap ? all_groups : kGroupCap);
+    const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries +
+                           (size_t)gcap * 16 /* cand_d2 */ + (size_t)N /* dmin */;
+    const size_t ints = entries + centries + (size_t)N /* sort keys */ + (size_t)N + (size_t)shares + g.n_rb + kMetaWords +
+                        (size_t)gcap /* glist */ + (size_t)gcap * 16 /* cand_j */ + (size_t)N /* pmin */;
     int rc = ensure(ctx, ctx->stage[7], doubles * sizeof(double) + ints * sizeof(int32_t) + 64);
     if (rc) return rc;
     double *rows_t = (double *)ctx->stage[7].p;
     double *psorted = rows_t + (size_t)g.Rp * E, *box = psorted + (size_t)N * E, *colbox = box + (size_t)N * 6;
     double *cmax = colbox + nJ * 6;
     double *pd = cmax + nJ, *cd = pd + entries;
-    int32_t *pj = (int32_t *)(cd + centries), *ci = pj + entries;
+    double *cand_d2 = cd + centries;
+    unsigned long long *dmin = (unsigned long long *)(cand_d2 + (size_t)gcap * 16);
+    int32_t *pj = (int32_t *)(dmin + N), *ci = pj + entries;
     unsigned *key = (unsigned *)(ci + centries);
     int32_t *perm = (int32_t *)(key + N), *surv = perm + N, *cnt = surv + shares, *meta = cnt + g.n_rb;
+    int32_t *glist = meta + kMetaWords, *cand_j = glist + gcap, *pmin = cand_j + (size_t)gcap * 16;
+    CullGroups cg{glist, dmin, pmin, cand_d2, cand_j, gcap, ctx->collide_cull_mode};
     ctx->collide_meta = meta;
     hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
                        ctx->stream, pos_cols, N, n_samples, box, key, meta);
@@ -1678,19 +1900,28 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_bound_kernel, dim3((N + kBoundRows - 1) / kBoundRows), dim3(kBoundRows * kBoundGroups), 0,
                        ctx->stream, (const double *)rows_t, g.Rp, N, n_samples, (const double *)box, (const int32_t *)perm,
-                       colbox, cmax);
+                       colbox, cmax, dmin, pmin);
     MSNAP_HIP(ctx, hipGetLastError());
     CollideCull cu{colbox, cmax};
-    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb), dim3(kSelThreads), 0, ctx->stream, N, cu, surv, cnt, meta);
+    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb + (unsigned)nJ), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
+                       surv, cnt, meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
+    // both evaluators are launched; each reads the two survivor counts and the one that is not chosen leaves at once
     const long long grid = shares * spmax < slots ? shares * spmax : slots;
     hipLaunchKernelGGL(collide_span_list_kernel, dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
                        (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, sp_force,
-                       (int)slots, meta);
+                       (int)slots, meta, cg);
+    MSNAP_HIP(ctx, hipGetLastError());
+    const long long ggrid = gcap < slots ? gcap : slots;
+    hipLaunchKernelGGL(collide_group_kernel, dim3((unsigned)ggrid), dim3(kWave), 0, ctx->stream, (const double *)psorted, N,
+                       n_samples, (const int32_t *)perm, (const int32_t *)meta, cg);
+    MSNAP_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(collide_resolve_kernel, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0, ctx->stream, N,
+                       (const int32_t *)meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                        ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)perm,
-                       (const int32_t *)cnt, (const int32_t *)meta);
+                       (const int32_t *)cnt, (const int32_t *)meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
@@ -1723,7 +1954,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)nullptr,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr);
+                     (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
@@ -1836,7 +2067,7 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   }
   hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, 0.0, out_d2, out_j, (int32_t *)nullptr, (const int32_t *)nullptr,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr);
+                     (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

@@ -83,6 +83,7 @@ struct msnap_ctx {
   int collide_sample_parts = 0; // "collide_sample_parts": waves per share of the pairwise pass (0: chosen per launch)
   int collide_no_sym = 0;       // "collide_no_sym": 1 = the rows of msnap_formation_collide are NOT the slice of the columns at row_offset: one-sided evaluation
   int collide_no_cull = 0;      // "collide_no_cull": 1 = whole-swarm passes without the exact broad phase (A/B, dense swarms)
+  int collide_cull_mode = 0;         // "collide_cull_mode": evaluator behind the broad phase: 0 chosen per pass, 1 surviving shares, 2 surviving group pairs
   int collide_cull_min_drones = 0;   // "collide_cull_min_drones": smallest whole swarm that takes the broad phase (0: default 3072)
   int collide_last_cull = 0;    // "collide_last_cull" (read): 1 if the last msnap_formation_collide took the broad-phase path
   int collide_last_shares = 0;  // "collide_last_shares" (read): 8-column x 128-row shares of that pass before the broad phase

@@ -244,18 +244,30 @@ def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
         got = ctx7.formation_collide(pos, pos, 0.3)
         assert ctx7.get_option("collide_last_cull") == 1
         shares, survivors = ctx7.get_option("collide_last_shares"), ctx7.get_option("collide_last_survivors")
-        for sp in (1, 3, 8):
+        groups = ctx7.get_option("collide_last_group_pairs")
+        ng = (n + 7) // 8
+        assert ng <= groups <= ng * (ng + 1) // 2
+        # both evaluators behind the broad phase: the surviving 128 x 8 shares (also with forced sample parts) and the
+        # surviving 8 x 8 group pairs
+        ctx7.set_option("collide_cull_mode", 2)
+        by_groups = ctx7.formation_collide(pos, pos, 0.3)
+        for a, b in zip(by_groups, ref):
+            np.testing.assert_array_equal(a, b)
+        ctx7.set_option("collide_cull_mode", 1)
+        for sp in (0, 1, 3, 8):
             ctx7.set_option("collide_sample_parts", sp)
             forced = ctx7.formation_collide(pos, pos, 0.3)
             for a, b in zip(forced, ref):
                 np.testing.assert_array_equal(a, b)
         ctx7.set_option("collide_sample_parts", 0)
+        ctx7.set_option("collide_cull_mode", 0)
         ctx7.set_option("collide_no_cull", 1)
         plain = ctx7.formation_collide(pos, pos, 0.3)
         assert ctx7.get_option("collide_last_cull") == 0
     finally:
         ctx7.set_option("collide_no_cull", 0)
         ctx7.set_option("collide_sample_parts", 0)
+        ctx7.set_option("collide_cull_mode", 0)
         ctx7.set_option("collide_cull_min_drones", 0)
     for a, b, c in zip(got, ref, plain):
         np.testing.assert_array_equal(a, b)

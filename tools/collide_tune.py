@@ -62,6 +62,7 @@ def main():
                               "broad_phase": bool(ctx.get_option("collide_last_cull")),
                               "shares": ctx.get_option("collide_last_shares"),
                               "survivors": ctx.get_option("collide_last_survivors"),
+                              "group_pairs": ctx.get_option("collide_last_group_pairs"),
                               "same_result": bool(same)}), flush=True)
     ctx.close()
 
