@@ -476,6 +476,9 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     # one rank, a whole swarm of 3072..8192 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
     broad = bool(ctx.get_option("collide_last_cull")) if world == 1 else False
     shares, survivors = (ctx.get_option("collide_last_shares"), ctx.get_option("collide_last_survivors")) if broad else (0, 0)
+    group_pairs = ctx.get_option("collide_last_group_pairs") if broad else 0
+    # the library's own rule (csrc/msnap_aux.hip::cull_use_groups): 8 x 8 group pairs when they are few against the shares
+    by_groups = broad and group_pairs <= (1 << 18) and group_pairs * 141 < survivors * 1485
     mesh_extra = None
     if cfg == 3:
         # how many point-triangle tests the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
@@ -500,8 +503,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     # what a rank evaluates: 1 / world of the swarm's (128-row block, column) units, each pair of them once; inside the
     # diagonal blocks both orders of a pair are computed (a 128 x 128 block instead of its triangle)
     pair_exec = (N * (N - 1) / 2 + 64.0 * N) / world * S * PAIR_OPS
-    if broad:       # the surviving shares: 128 rows x 8 columns each
-        pair_exec = survivors * 128.0 * 8.0 * S * PAIR_OPS
+    if broad:       # the surviving shares (128 rows x 8 columns each) or the surviving group pairs (8 x 8)
+        pair_exec = (group_pairs * 64.0 if by_groups else survivors * 128.0 * 8.0) * S * PAIR_OPS
     rep = {
         "workload": f"configs[{cfg}]: {N} drones x {M} segments, order 7, formation-like swarm ({G} rigid bodies x "
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
@@ -527,23 +530,26 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                           "time grids takes), outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "pairwise": {"kernel": (("msnap::collide_key_kernel + collide_rank_kernel + collide_transpose_kernel + "
-                                     "collide_bound_kernel + collide_select_kernel + collide_span_list_kernel + "
-                                     "collide_merge_kernel (exact broad phase; the same arithmetic on the surviving shares)"
+            "pairwise": {"kernel": ((("msnap::collide_key_kernel + collide_rank_kernel + collide_transpose_kernel + "
+                                      "collide_bound_kernel + collide_select_kernel + collide_eval_kernel + "
+                                      "collide_resolve_kernel + collide_merge_kernel (exact broad phase; the same arithmetic "
+                                      "on the surviving ") + ("8 x 8 group pairs)" if by_groups else "128 x 8 shares)")
                                      if broad else
                                      "msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)")
                                     if world == 1 else "msnap::collide_transpose_kernel + collide_span_kernel + "
                                     "collide_merge_kernel on this rank's part of the swarm's pairs"),
                          "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": pair_once,
-                         "broad_phase": ({"shares": shares, "shares_evaluated": survivors,
-                                          "cull_ratio": survivors / shares} if broad else None),
+                         "broad_phase": ({"shares": shares, "shares_surviving": survivors,
+                                          "group_pairs": (N // 8) * (N // 8 + 1) // 2, "group_pairs_surviving": group_pairs,
+                                          "evaluated": "group pairs" if by_groups else "shares",
+                                          "cull_ratio": pair_exec / S / PAIR_OPS / (N * (N - 1) / 2)} if broad else None),
                          # the work the kernels evaluate (with the broad phase: the surviving shares) over time and peak
                          "frac": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "frac_on_all_pairs": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "tflops_on_all_pairs": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
                          "frac_of_attainable": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS / PAIR_MIX_ATTAINABLE,
                          "note": "frac = the pair-samples the kernels evaluate (N(N-1)/2 + the doubled triangle of the "
-                                 "diagonal blocks; behind the broad phase: 128 x 8 per surviving share) x 7 vector "
+                                 "diagonal blocks; behind the broad phase: 128 x 8 per surviving share or 8 x 8 per surviving group pair) x 7 vector "
                                  "instructions (3 differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md "
                                  "8d) / the stage's time -- sort, bounds, selection and merge included -- / the fp64 issue "
                                  "peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); frac_on_all_pairs credits every unordered "

@@ -1023,92 +1023,142 @@ __device__ __host__ __forceinline__ bool cull_use_groups(int shares, int groups,
   return (long long)groups * 141 < (long long)shares * 1485;
 }
 
-// One workgroup per row block: thread k tests share k (at most 1024 of them: kCullMaxDrones / 8); the survivors are
+// One workgroup per row block: its threads test the shares (at most 1024 of them: kCullMaxDrones / 8); the survivors are
 // written, in ascending order, to a range of the list that the workgroup reserves with one atomic add -- the row
 // blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
-constexpr int kSelThreads = 1024;
+constexpr int kSelThreads = 256;
+constexpr int kSelGroups = 8;      // group-pair selection: a's per workgroup
+constexpr int kSelTrips = 4;      // shares of a row block: at most kCullMaxDrones / 8 = kSelTrips * kSelThreads
 __global__ void __launch_bounds__(kSelThreads)
 collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt,
                       int32_t *__restrict__ meta, CullGroups cg) {
   if ((int)blockIdx.x >= n_rb) {
-    // group pairs (a, b), a <= b: workgroup a tests every b (the same strict test on the two groups' boxes and bounds);
-    // the survivors of a workgroup are appended with one atomic reservation, the workgroups in no particular order
-    __shared__ double sA[8];
-    const int a = blockIdx.x - n_rb, nG = (N + kColBlock - 1) / kColBlock, lane = threadIdx.x & (kWave - 1);
-    if (threadIdx.x < 7) sA[threadIdx.x] = threadIdx.x < 6 ? cu.colbox[(size_t)a * 6 + threadIdx.x] : cu.cmax[a];
-    __syncthreads();
-    __shared__ int gsum[kSelThreads / kWave];
+    // group pairs (a, b), a <= b: a workgroup takes kSelGroups a's and tests each against every b (the same strict test
+    // on the two groups' boxes and bounds); its survivors are appended with ONE atomic reservation -- a reservation per
+    // a was 512 atomics on one word, 20 ns apiece -- the workgroups in no particular order
+    constexpr int NW = kSelThreads / kWave, NS = kSelGroups * kSelTrips;
+    __shared__ int gsum[NS * NW + 1];
     __shared__ int gbase;
-    const int w = threadIdx.x / kWave;
-    for (int b0 = a; b0 < nG; b0 += kSelThreads) {
-      const int b = b0 + threadIdx.x;
-      bool keep = false;
-      if (b < nG) {
-        keep = b == a;
-        if (!keep) {
-          const double lb2 = box_box_lb2(sA, cu.colbox + (size_t)b * 6);
-          keep = !((lb2 > sA[6]) & (lb2 > cu.cmax[b]));
-        }
-      }
-      const unsigned long long m = __ballot(keep);
-      if (lane == 0) gsum[w] = __popcll(m);
-      __syncthreads();
-      int off = 0, all = 0;
+    const int a0 = (blockIdx.x - n_rb) * kSelGroups, nG = (N + kColBlock - 1) / kColBlock;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    unsigned kept = 0;      // bit (ai * kSelTrips + t): pair (a0 + ai, a + t * kSelThreads + thread) survives
 #pragma unroll
-      for (int q = 0; q < kSelThreads / kWave; ++q) {
-        const int v = gsum[q];
-        off += q < w ? v : 0;
-        all += v;
+    for (int ai = 0; ai < kSelGroups; ++ai) {
+      const int a = a0 + ai;
+      double A[7];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) A[k] = cu.colbox[(size_t)(a < nG ? a : nG - 1) * 6 + k];
+      A[6] = cu.cmax[a < nG ? a : nG - 1];
+#pragma unroll
+      for (int t = 0; t < kSelTrips; ++t) {      // (at most kCullMaxDrones / 8 groups)
+        bool keep = false;
+        if (a + t * kSelThreads < nG) {      // (wave-uniform)
+          const int b = a + t * kSelThreads + threadIdx.x, bc = b < nG ? b : nG - 1;
+          const double lb2 = box_box_lb2(A, cu.colbox + (size_t)bc * 6);
+          keep = b < nG && (b == a || !((lb2 > A[6]) & (lb2 > cu.cmax[bc])));
+        }
+        const unsigned long long m = __ballot(keep);
+        kept |= keep ? 1u << (ai * kSelTrips + t) : 0u;
+        if (lane == 0) gsum[(ai * kSelTrips + t) * NW + w] = __popcll(m);
       }
-      if (threadIdx.x == 0) gbase = atomicAdd(&meta[kMetaGroups], all);      // one reservation per workgroup and trip
-      __syncthreads();
-      const int pos = gbase + off + __popcll(m & ((1ull << lane) - 1ull));
-      if (keep && pos < cg.cap) cg.glist[pos] = (a << 16) | b;
-      __syncthreads();
     }
+    __syncthreads();
+    // exclusive scan of the NS x NW wave counts (two wavefronts' worth)
+    if (threadIdx.x < kWave) {
+      int run = 0;
+      for (int i0 = 0; i0 < NS * NW; i0 += kWave) {
+        const int v = i0 + lane < NS * NW ? gsum[i0 + lane] : 0;
+        int inc = v;
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+          const int o = __shfl_up(inc, m);
+          inc += lane >= m ? o : 0;
+        }
+        if (i0 + lane < NS * NW) gsum[i0 + lane] = run + inc - v;
+        run += __shfl(inc, kWave - 1);
+      }
+      if (lane == 0) gbase = atomicAdd(&meta[kMetaGroups], run);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ai = 0; ai < kSelGroups; ++ai)
+#pragma unroll
+      for (int t = 0; t < kSelTrips; ++t) {
+        const bool keep = (kept >> (ai * kSelTrips + t)) & 1u;
+        const unsigned long long m = __ballot(keep);
+        const int pos = gbase + gsum[(ai * kSelTrips + t) * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && pos < cg.cap) cg.glist[pos] = ((a0 + ai) << 16) | (a0 + ai + t * kSelThreads + threadIdx.x);
+      }
     return;
   }
   constexpr int GPB = kRowBlock / kColBlock;      // groups of 8 per row block
-  __shared__ int wsum[kSelThreads / kWave];
+  constexpr int NW = kSelThreads / kWave;
+  __shared__ int wsum[kSelTrips][NW];
   __shared__ int sStart;
   __shared__ double sRow[GPB][8];      // the row block's own groups: box, largest bound
+  __shared__ double sAll[8];           // their union, the largest of their bounds
   const int I = blockIdx.x, lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-  const int nsh = (N - I * kRowBlock + kColBlock - 1) / kColBlock;
+  const int nsh = (N - I * kRowBlock + kColBlock - 1) / kColBlock;      // <= kSelTrips * kSelThreads (kCullMaxDrones)
   const int ng = nsh < GPB ? nsh : GPB;
   if (threadIdx.x < 7 * GPB) {
     const int q = threadIdx.x / 7, k = threadIdx.x % 7;
     if (q < ng) sRow[q][k] = k < 6 ? cu.colbox[(size_t)(I * GPB + q) * 6 + k] : cu.cmax[I * GPB + q];
   }
   __syncthreads();
-  const int k = threadIdx.x;
-  bool keep = false;
-  if (k < nsh) {
-    keep = true;
-    if (k >= GPB) {
-      // Skip the share unless some pair of it could reach (or tie) a minimum of its row or its column: the rows are
-      // taken group by group -- a block of 128 consecutive drones of the sorted order can straddle a jump of the
-      // curve, its groups of 8 hardly ever do.
-      const int J = I * GPB + k;
-      double cb[6];
+  // the union of the row block's groups: a share that fails against it fails against every group (most do, and whole
+  // wavefronts of them: the group-by-group test below is 16 box distances per share)
+  if (threadIdx.x < 7) {
+    const int k = threadIdx.x;
+    double v = sRow[0][k];
+    for (int q = 1; q < ng; ++q) v = k < 3 ? fmin(v, sRow[q][k]) : fmax(v, sRow[q][k]);
+    sAll[k] = v;
+  }
+  __syncthreads();
+  unsigned long long mk[kSelTrips];
+  bool keep[kSelTrips];
+  // (the column groups' boxes of all trips are fetched before the first test: one memory round trip, not four)
+  double cbx[kSelTrips][6], cmx[kSelTrips];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) cb[c] = cu.colbox[(size_t)J * 6 + c];
-      const double cm = cu.cmax[J];
-      keep = false;
-      for (int q = 0; q < ng; ++q) {
-        const double lb2 = box_box_lb2(sRow[q], cb);
-        keep |= !((lb2 > sRow[q][6]) & (lb2 > cm));
+  for (int t = 0; t < kSelTrips; ++t) {
+    const int k = t * kSelThreads + threadIdx.x, J = I * GPB + (k < nsh ? k : nsh - 1);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) cbx[t][c] = cu.colbox[(size_t)J * 6 + c];
+    cmx[t] = cu.cmax[J];
+  }
+#pragma unroll
+  for (int t = 0; t < kSelTrips; ++t) {
+    const int k = t * kSelThreads + threadIdx.x;
+    keep[t] = false;
+    if (k < nsh) {
+      keep[t] = true;
+      if (k >= GPB) {
+        // Skip the share unless some pair of it could reach (or tie) a minimum of its row or its column: the rows are
+        // taken group by group -- a block of 128 consecutive drones of the sorted order can straddle a jump of the
+        // curve, its groups of 8 hardly ever do.
+        const double cm = cmx[t];
+        bool any = false;
+        const double lb0 = box_box_lb2(sAll, cbx[t]);
+        if (!((lb0 > sAll[6]) & (lb0 > cm))) {
+          for (int q = 0; q < ng; ++q) {
+            const double lb2 = box_box_lb2(sRow[q], cbx[t]);
+            any |= !((lb2 > sRow[q][6]) & (lb2 > cm));
+          }
+        }
+        keep[t] = any;
       }
     }
+    mk[t] = __ballot(keep[t]);
+    if (lane == 0) wsum[t][w] = __popcll(mk[t]);
   }
-  const unsigned long long m = __ballot(keep);
-  if (lane == 0) wsum[w] = __popcll(m);
   __syncthreads();
-  int off = 0, all = 0;
+  int all = 0, off[kSelTrips];
 #pragma unroll
-  for (int q = 0; q < kSelThreads / kWave; ++q) {
-    const int v = wsum[q];
-    off += q < w ? v : 0;
-    all += v;
+  for (int t = 0; t < kSelTrips; ++t) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      if (q == w) off[t] = all;      // (all: the survivors with a lower share number so far)
+      all += wsum[t][q];
+    }
   }
   if (threadIdx.x == 0) {
     const int start = atomicAdd(&meta[kMetaTotal], all);
@@ -1117,23 +1167,24 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
     cnt[I] = all;
   }
   __syncthreads();
-  if (keep) list[sStart + off + __popcll(m & ((1ull << lane) - 1ull))] = (I << 16) | k;
+#pragma unroll
+  for (int t = 0; t < kSelTrips; ++t)
+    if (keep[t]) list[sStart + off[t] + __popcll(mk[t] & ((1ull << lane) - 1ull))] = (I << 16) | (t * kSelThreads + threadIdx.x);
 }
 
 // The surviving shares, walked by a fixed grid of waves: item it = (survivor it / sp, sample part it % sp) of the
 // list; its row-side partial entry is entry `it` of part_d2 / part_j, the column side goes to the (row block,
 // sample part) slots as in the plain pass.  The next item's list entry is fetched before the current item runs.
-__global__ void __launch_bounds__(kWave, 4)
-collide_span_list_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
-                         double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
-                         int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
-                         int sp_force, int slots, int32_t *__restrict__ meta, CullGroups cg) {
+__device__ __forceinline__ void
+collide_span_list_body(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
+                       double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                       int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
+                       int sp_force, int slots, int32_t *__restrict__ meta) {
   constexpr int CB = kColBlock;
   __shared__ double sFold[CB * kWave];
   __shared__ int sFoldI[CB * kWave];
   const int lane = threadIdx.x;
   const int tot = meta[kMetaTotal];
-  if (cull_use_groups(tot, meta[kMetaGroups], cg)) return;      // this pass is evaluated group pair by group pair
   const CullSplit sp = cull_split(tot, slots, cull_nch(g.S), sp_force);
   if (blockIdx.x == 0 && lane == 0) {
     meta[kMetaParts] = sp.lo;
@@ -1193,13 +1244,12 @@ collide_span_list_kernel(const double *__restrict__ prow_t, const double *__rest
 constexpr int kGroupHalf = kColBlock / 2;
 constexpr int kGroupCap = 1 << 18;      // group pairs the list holds (all 131 328 of 4096 drones; 8192 have 524 800)
 constexpr int kGroupLanes = kWave / 2;  // samples per trip
-__global__ void __launch_bounds__(kWave, 3)
-collide_group_kernel(const double *__restrict__ pcol, int N, int S, const int32_t *__restrict__ oid,
-                     const int32_t *__restrict__ meta, CullGroups cg) {
+__device__ __forceinline__ void
+collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t *__restrict__ oid,
+                   const int32_t *__restrict__ meta, const CullGroups &cg) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x;
   const int tot = meta[kMetaGroups];
-  if (!cull_use_groups(meta[kMetaTotal], tot, cg)) return;
   const unsigned stride = (unsigned)S * 3u;
   const int half = lane >> 5, ls = lane & (kGroupLanes - 1);
   // this lane's pair after the butterfly
@@ -1290,6 +1340,19 @@ collide_group_kernel(const double *__restrict__ pcol, int N, int S, const int32_
       }
     }
   }
+}
+
+// The evaluator behind the broad phase: ONE launch of a fixed grid of waves that reads the two survivor counts and walks
+// either the surviving shares or the surviving group pairs (cull_use_groups).
+__global__ void __launch_bounds__(kWave, 4)
+collide_eval_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
+                    double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                    int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
+                    int sp_force, int slots, int32_t *__restrict__ meta, CullGroups cg) {
+  if (cull_use_groups(meta[kMetaTotal], meta[kMetaGroups], cg))
+    collide_group_body(pcol, g.R, g.S, oid, meta, cg);
+  else
+    collide_span_list_body(prow_t, pcol, g, part_d2, part_j, cpart_d2, cpart_i, oid, list, sp_force, slots, meta);
 }
 
 // Every candidate that equals its drone's minimum bids for the partner: the lowest ORIGINAL index wins, as in the
@@ -1903,18 +1966,12 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                        colbox, cmax, dmin, pmin);
     MSNAP_HIP(ctx, hipGetLastError());
     CollideCull cu{colbox, cmax};
-    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb + (unsigned)nJ), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
+    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb + (unsigned)((nJ + kSelGroups - 1) / kSelGroups)), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
                        surv, cnt, meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
-    // both evaluators are launched; each reads the two survivor counts and the one that is not chosen leaves at once
-    const long long grid = shares * spmax < slots ? shares * spmax : slots;
-    hipLaunchKernelGGL(collide_span_list_kernel, dim3((unsigned)grid), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
+    hipLaunchKernelGGL(collide_eval_kernel, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
                        (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, sp_force,
                        (int)slots, meta, cg);
-    MSNAP_HIP(ctx, hipGetLastError());
-    const long long ggrid = gcap < slots ? gcap : slots;
-    hipLaunchKernelGGL(collide_group_kernel, dim3((unsigned)ggrid), dim3(kWave), 0, ctx->stream, (const double *)psorted, N,
-                       n_samples, (const int32_t *)perm, (const int32_t *)meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_resolve_kernel, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0, ctx->stream, N,
                        (const int32_t *)meta, cg);

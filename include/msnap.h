@@ -108,8 +108,12 @@ int msnap_host_free(void *ptr);
  *                          evaluate every pair; results are identical either way (a dense swarm, where nothing
  *                          can be culled, saves the sort: about a sixth of the pass at 4096 drones).  Read-only
  *                          companions: "collide_last_cull" (1 if the last pass took the broad phase),
- *                          "collide_last_shares" (its shares before the test) and "collide_last_survivors"
- *                          (the shares it evaluated; synchronises the stream)
+ *                          "collide_last_shares" (its 128 x 8 shares before the test), "collide_last_survivors"
+ *                          (the shares that pass it) and "collide_last_group_pairs" (the 8 x 8 group pairs that
+ *                          pass it; both synchronise the stream)
+ *   "collide_cull_mode"    what the broad phase evaluates: 0 (default) chosen per pass on the device -- the surviving
+ *                          8 x 8 group pairs when they are few against the surviving 128 x 8 shares --, 1 always
+ *                          the shares, 2 always the group pairs (while their list holds them: 262144)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
@@ -123,8 +127,8 @@ int msnap_host_free(void *ptr);
  *                          the old handle -- e.g. torch.cuda.ExternalStream -- would dangle)
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
  * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
- * MSNAP_COLLIDE_SAMPLE_PARTS, MSNAP_COLLIDE_NO_CULL, MSNAP_COLLIDE_CULL_MIN_DRONES and
- * MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
+ * MSNAP_COLLIDE_SAMPLE_PARTS, MSNAP_COLLIDE_NO_CULL, MSNAP_COLLIDE_CULL_MIN_DRONES,
+ * MSNAP_COLLIDE_CULL_MODE and MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
 int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value);
 /* hipEvent timing on the context's stream (bench.py roofline leg). */

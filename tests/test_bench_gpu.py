@@ -45,7 +45,9 @@ def test_bench_line_contract():
     assert set(cfg["3"]["stage_us"]) == {"solve", "sample", "pairwise", "mesh"}
     pw = cfg["2"]["stages"]["pairwise"]
     assert 0.0 < pw["frac"] < 1.0 and pw["frac_on_all_pairs"] >= pw["frac"]
-    assert pw["broad_phase"] is not None and 0 < pw["broad_phase"]["shares_evaluated"] <= pw["broad_phase"]["shares"]
+    bp = pw["broad_phase"]
+    assert bp is not None and 0 < bp["shares_surviving"] <= bp["shares"] and 0 < bp["group_pairs_surviving"] <= bp["group_pairs"]
+    assert 0.0 < bp["cull_ratio"] < 1.0
     assert cfg["2"]["stages"]["pairwise"]["pairs_evaluated_once_over_all_ranks"] is True
     assert cfg["4"]["stages"]["solve"]["kernel"] == "msnap::solve_kernel_twin<5, 10>"      # what the library says it launched
     assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-9
