@@ -473,7 +473,7 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
     k1_kernel = ctx.last_kernel()
     pair_once = bool(ctx.get_option("collide_last_sym")) if world == 1 else True   # (parts: by construction)
-    # one rank, a whole swarm of 3072..8192 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
+    # one rank, a whole swarm of 3072..16384 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
     broad = bool(ctx.get_option("collide_last_cull")) if world == 1 else False
     shares, survivors = (ctx.get_option("collide_last_shares"), ctx.get_option("collide_last_survivors")) if broad else (0, 0)
     group_pairs = ctx.get_option("collide_last_group_pairs") if broad else 0
@@ -728,7 +728,7 @@ def main():
                 strong = {"n_gpus": world,
                           "note": "total work fixed and sharded by drone over the ranks; value = drones / max-over-ranks time; "
                                   "the formation pipelines include both collectives of the pairwise pass.  One GPU runs a "
-                                  "whole swarm of 3072..8192 drones behind the exact broad phase of the pairwise pass "
+                                  "whole swarm of 3072..16384 drones behind the exact broad phase of the pairwise pass "
                                   "(formation_4096x10); the sharded pass evaluates every pair, 1 / n_gpus of them per rank, "
                                   "so its curve starts from formation_4096x10_all_pairs -- and at 4096 drones one GPU "
                                   "behind the broad phase is faster than two or four ranks with their two collectives",

@@ -247,7 +247,7 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
     int32_t n = 0;
     if (ctx->collide_last_cull && ctx->collide_meta) {
       if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-          hipMemcpy(&n, ctx->collide_meta + 68, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+          hipMemcpy(&n, ctx->collide_meta + MSNAP_COLLIDE_META_GROUPS, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     }
     *value = n;
@@ -257,7 +257,7 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
     int32_t n = 0;
     if (ctx->collide_last_cull && ctx->collide_meta) {
       if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-          hipMemcpy(&n, ctx->collide_meta + 64, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+          hipMemcpy(&n, ctx->collide_meta + MSNAP_COLLIDE_META_SHARES, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     } else {
       n = ctx->collide_last_shares;

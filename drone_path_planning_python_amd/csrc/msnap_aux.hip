@@ -965,17 +965,21 @@ struct CullSplit {
   // first item of list position f
   __device__ __host__ __forceinline__ int item_of(int f) const { return f <= x ? f * hi : x * hi + (f - x) * lo; }
 };
+// `force`: bits 0..7 a part count to use whatever the estimate says (0: none), bits 8.. the largest part count the
+// column-side slots of this launch were laid out for (0: kCullMaxParts)
 __device__ __host__ __forceinline__ CullSplit cull_split(int tot, int slots, int nch, int force) {
   CullSplit c;
   c.x = 0;
+  const int maxp = (force >> 8) > 0 && (force >> 8) < kCullMaxParts ? (force >> 8) : kCullMaxParts;
+  force &= 0xff;
   if (force > 0) {
-    c.lo = c.hi = force < kCullMaxParts ? force : kCullMaxParts;
+    c.lo = c.hi = force < maxp ? force : maxp;
     return c;
   }
   const int simds = slots / 4 > 0 ? slots / 4 : 1;
   int best = 1;
   long long best_cost = -1;
-  for (int sp = 1; sp <= kCullMaxParts && (sp == 1 || nch / sp >= 2); ++sp) {
+  for (int sp = 1; sp <= maxp && (sp == 1 || nch / sp >= 2); ++sp) {
     const long long serial = ((long long)tot * sp + simds - 1) / simds;
     const long long cost = serial * (17 * ((nch + sp - 1) / sp) + 15);      // 0.1 us
     if (best_cost < 0 || cost < best_cost) {
@@ -994,11 +998,11 @@ __device__ __host__ __forceinline__ int cull_nch(int S) {
 
 // what the broad-phase kernels hand each other (int32 words in device memory)
 enum : int {
-  kMetaStart = 0,      // [n_rb <= 64] first list position of row block I's survivors
-  kMetaTotal = 64,     // surviving shares (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
-  kMetaParts = 65,     // CullSplit lo, hi, x (collide_span_list_kernel, for the merge)
-  kMetaGroups = 68,    // surviving GROUP PAIRS (zeroed and reserved like kMetaTotal)
-  kMetaWords = 70
+  kMetaStart = 0,                           // [n_rb <= 128] first list position of row block I's survivors
+  kMetaTotal = MSNAP_COLLIDE_META_SHARES,   // surviving shares (the list's length; zeroed by collide_key_kernel, reserved atomically by the selection)
+  kMetaParts = kMetaTotal + 1,              // CullSplit lo, hi, x (the share evaluator, for the merge)
+  kMetaGroups = MSNAP_COLLIDE_META_GROUPS,  // surviving GROUP PAIRS (zeroed and reserved like kMetaTotal)
+  kMetaWords = kMetaGroups + 2
 };
 
 // The second granularity of the broad phase: pairs of GROUPS (8 x 8 drones of the sorted order).  Of a surviving share
@@ -1028,7 +1032,7 @@ __device__ __host__ __forceinline__ bool cull_use_groups(int shares, int groups,
 // blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
 constexpr int kSelThreads = 256;
 constexpr int kSelGroups = 8;      // group-pair selection: a's per workgroup
-constexpr int kSelTrips = 4;      // shares of a row block: at most kCullMaxDrones / 8 = kSelTrips * kSelThreads
+constexpr int kSelTrips = 8;      // shares of a row block: at most kCullMaxDrones / 8 = kSelTrips * kSelThreads
 __global__ void __launch_bounds__(kSelThreads)
 collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt,
                       int32_t *__restrict__ meta, CullGroups cg) {
@@ -1041,7 +1045,7 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
     __shared__ int gbase;
     const int a0 = (blockIdx.x - n_rb) * kSelGroups, nG = (N + kColBlock - 1) / kColBlock;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    unsigned kept = 0;      // bit (ai * kSelTrips + t): pair (a0 + ai, a + t * kSelThreads + thread) survives
+    unsigned long long kept = 0;      // bit (ai * kSelTrips + t): pair (a0 + ai, a + t * kSelThreads + thread) survives
 #pragma unroll
     for (int ai = 0; ai < kSelGroups; ++ai) {
       const int a = a0 + ai;
@@ -1058,7 +1062,7 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
           keep = b < nG && (b == a || !((lb2 > A[6]) & (lb2 > cu.cmax[bc])));
         }
         const unsigned long long m = __ballot(keep);
-        kept |= keep ? 1u << (ai * kSelTrips + t) : 0u;
+        kept |= keep ? 1ull << (ai * kSelTrips + t) : 0ull;
         if (lane == 0) gsum[(ai * kSelTrips + t) * NW + w] = __popcll(m);
       }
     }
@@ -1084,7 +1088,7 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
     for (int ai = 0; ai < kSelGroups; ++ai)
 #pragma unroll
       for (int t = 0; t < kSelTrips; ++t) {
-        const bool keep = (kept >> (ai * kSelTrips + t)) & 1u;
+        const bool keep = (kept >> (ai * kSelTrips + t)) & 1ull;
         const unsigned long long m = __ballot(keep);
         const int pos = gbase + gsum[(ai * kSelTrips + t) * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
         if (keep && pos < cg.cap) cg.glist[pos] = ((a0 + ai) << 16) | (a0 + ai + t * kSelThreads + threadIdx.x);
@@ -1680,7 +1684,7 @@ collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restr
 // drones -- over 256 workgroups; counting in the lanes (a compare and an add-with-carry per pair, 64 drones per
 // workgroup) took 8-10 us, a 78-stage bitonic network in one workgroup 36 us.
 // perm[sorted position] = original index.
-constexpr int kCullMaxDrones = 8192;
+constexpr int kCullMaxDrones = 16384;
 constexpr int kCullMinDrones = 3072;
 constexpr int kRankWaves = 16;
 constexpr int kRankTile = 16;
@@ -1923,11 +1927,13 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     const size_t nJ = ((size_t)N + kColBlock - 1) / kColBlock;
     long long shares = 0;
     for (int I = 0; I < g.n_rb; ++I) shares += (N - I * kRowBlock + kColBlock - 1) / kColBlock;
-    const int spmax = kCullMaxParts;
+    // sample parts a share may be cut into: the column-side slots are n_rb x spmax x N entries, pre-filled per call
+    const int spmax = N > 8192 ? 2 : kCullMaxParts;
     ctx->collide_last_shares = (int)shares;
-    const int sp_force = ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0;
+    const int sp_force = (ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0) |
+                         (spmax << 8);
     // row-side entries: one per item; cull_split cuts shares only to fill the wave slots once
-    const long long items_max = sp_force ? shares * sp_force : (shares > slots ? shares : slots);
+    const long long items_max = (sp_force & 0xff) ? shares * (sp_force & 0xff) : (shares > slots ? shares : slots);
     const size_t entries = (size_t)items_max * kRowBlock;
     const size_t centries = (size_t)g.n_rb * spmax * N;
     // group-pair path (CullGroups): list, candidate slots (16 per item), per-drone atomics

@@ -8,6 +8,9 @@
 #include "../../include/msnap.h"
 
 #define MSNAP_VERSION_NUM 100  /* 0.1.0 */
+/* int32 words of the pairwise pass's broad-phase hand-over block that msnap_get_option reads back */
+#define MSNAP_COLLIDE_META_SHARES 128
+#define MSNAP_COLLIDE_META_GROUPS 132
 
 namespace msnap {
 

@@ -103,7 +103,7 @@ int msnap_host_free(void *ptr);
  *                          "collide_last_sym": 1 if the last pass evaluated its own-range pairs once)
  *   "collide_cull_min_drones"  smallest whole swarm that takes the exact broad phase (0 = default 3072; at least
  *                          256: tests lower it to check the path against the oracle on small swarms)
- *   "collide_no_cull"      1: whole-swarm passes (row_offset 0, n_rows == n_cols, 3072..8192 drones) skip the exact
+ *   "collide_no_cull"      1: whole-swarm passes (row_offset 0, n_rows == n_cols, 3072..16384 drones) skip the exact
  *                          broad phase -- spatial sort, per-drone bounds, box test per 8-column share -- and
  *                          evaluate every pair; results are identical either way (a dense swarm, where nothing
  *                          can be culled, saves the sort: about a sixth of the pass at 4096 drones).  Read-only

@@ -227,7 +227,7 @@ def _broad_phase_swarm(kind, n, S, rng):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,S", [("dense", 300, 19), ("sparse", 256, 91), ("sparse", 1000, 37), ("sparse", 2049, 13),
                                       ("teams", 777, 24), ("teams", 1536, 91), ("far", 600, 30), ("sparse", 513, 6),
-                                      ("teams", 3072, 12)])
+                                      ("teams", 3072, 12), ("sparse", 9001, 7), ("teams", 16384, 6)])
 def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
     """The whole-swarm pass behind its exact broad phase (spatial sort, per-drone bounds, box test per 8-column share,
     surviving shares only): distances, partners and hits bit for bit those of the oracle's all-pairs pass -- with failed

@@ -15,6 +15,7 @@ cp $P/pmc_traffic.json profiles/pmc_traffic.json
 cp $Q/pipeline_summary.md profiles/${TAG}_pipeline_summary.md
 cp $Q/config2.json profiles/${TAG}_config2_pipeline.json
 cp $Q/config3.json profiles/${TAG}_config3_pipeline.json
+[ -f $Q/config2_all_pairs.json ] && cp $Q/config2_all_pairs.json profiles/${TAG}_config2_all_pairs_pipeline.json
 cp $Q/pmc_counters.json profiles/pmc_counters.json
 python3 - "$TAG" <<'PY'
 import json, sys
@@ -35,6 +36,13 @@ if [ -f gpurun_out/${TAG}_order_sizes.txt ]; then
     echo "# Per size three lines: the launcher's choice, with no_twist (small batches off the two-sided latency kernel), with no_twist + no_twin"
     echo "# (solve_kernel_reg).  Order 9 (configs[4] = 65536 x 10; sharded over 8 GPUs: 8192 per rank), then order 7, then odd / longer paths."
     cat gpurun_out/${TAG}_order_sizes.txt; } > profiles/${TAG}_order_sizes.txt
+fi
+if [ -f gpurun_out/${TAG}_cull_sweep.txt ]; then
+  { echo "# tools/cull_sweep.sh: the pairwise pass behind its exact broad phase.  Fixture = the configs[2] pipeline (us per pipeline, stage"
+    echo "# times); MODE 0 = evaluator chosen per pass on the device, 1 = surviving 128 x 8 shares, 2 = surviving 8 x 8 group pairs; then"
+    echo "# tools/collide_tune.py on dense (every sample anywhere in a 100 m cube: nothing can be culled) and sparse (SPREAD=400: drones 3 m"
+    echo "# apart over 400 x 400 m) synthetic swarms, and with the broad phase off (NO_CULL)."
+    cat gpurun_out/${TAG}_cull_sweep.txt; } > profiles/${TAG}_cull_sweep.txt
 fi
 if [ -f gpurun_out/${TAG}_collide_sizes.jsonl ]; then
   { echo "# tools/collide_tune.py <N> 91 (WPC=0: the launcher's own geometry; 25 warm + 20 timed launches): transposition + span + merge of one"

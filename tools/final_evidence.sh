@@ -12,6 +12,7 @@ python3 bench.py > gpurun_out/${TAG}_bench_final.json 2> gpurun_out/${TAG}_bench
 (for n in 256 512 1024 2048 3072 4096 6144 8192; do WPC=0 python3 tools/collide_tune.py $n 91; done
  WPC=0 python3 tools/collide_tune.py 8192 96; WPC=0 python3 tools/collide_tune.py 4096 96
  python3 tools/collide_parts.py 4096 91 2 4 8; python3 tools/collide_parts.py 16384 91 8) 2>&1 | grep "^{" > gpurun_out/${TAG}_collide_sizes.jsonl
+NS="2048 4096 8192" bash tools/cull_sweep.sh && cp gpurun_out/cull_sweep.log gpurun_out/${TAG}_cull_sweep.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_parts -- python3 tools/collide_parts.py 4096 91 2 4 8 > /dev/null 2>&1
 python3 tools/prof_summary.py gpurun_out/prof_${TAG}_parts gpurun_out/${TAG}_collide_parts_kernels.md > /dev/null
 rm -rf gpurun_out/prof_${TAG}_parts

@@ -13,6 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/aux -- python3 tool
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p49 -- python3 tools/node_path49.py > $OUT/node_path49.txt 2> $OUT/p49.err || { tail -3 $OUT/p49.err; exit 1; }
 # vector-instruction counts of the two collision kernels on the same workload (bench.py's mesh roofline)
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 tools/formation_pipeline.py --config 3 --reps 10 > /dev/null 2> $OUT/pmc3.err || exit 1
+# the all-pairs kernel of the pairwise pass on the same workload (broad phase off: dense swarms, shards, parts)
+export MSNAP_COLLIDE_NO_CULL=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c2all -- python3 tools/formation_pipeline.py --config 2 --reps 30 > $OUT/config2_all_pairs.json 2> $OUT/c2all.err || { tail -3 $OUT/c2all.err; exit 1; }
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc3all -- python3 tools/formation_pipeline.py --config 3 --reps 10 > /dev/null 2> $OUT/pmc3all.err || exit 1
+unset MSNAP_COLLIDE_NO_CULL
 python3 - "$OUT" <<'PY'
 import csv, glob, json, os, sys, collections
 sys.path.insert(0, os.getcwd())
@@ -21,6 +26,7 @@ out = sys.argv[1]
 with open(out + "/pipeline_summary.md", "w") as f:
     for tag, title in (("c2", "configs[2]: 4096 drones x 10 segments (formation fixture), 91 samples, pairwise pass"),
                        ("c3", "configs[3]: 4096 drones x 20 segments (formation fixture), 96 samples, pairwise pass + 68-triangle STL scene"),
+                       ("c2all", "configs[2] with the pairwise pass's broad phase off (MSNAP_COLLIDE_NO_CULL=1): the all-pairs kernel"),
                        ("aux", "streaming kernels at 2^18 drones x 10 segments (tools/aux_bench.py)"),
                        ("p49", "the reference's live shape: 50-pose rigid-body path -> transform -> paths_to_pols, 2 drones x 49 segments (tools/node_path49.py)")):
         path = glob.glob(f"{out}/{tag}/**/*kernel_stats.csv", recursive=True)[0]
@@ -33,9 +39,10 @@ with open(out + "/pipeline_summary.md", "w") as f:
                                                            float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
         f.write("\n")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for fn in glob.glob(f"{out}/pmc3/**/*counter_collection.csv", recursive=True):
+    for fn in glob.glob(f"{out}/pmc3/**/*counter_collection.csv", recursive=True) + glob.glob(f"{out}/pmc3all/**/*counter_collection.csv", recursive=True):
+        allp = "/pmc3all/" in fn
         for r in csv.DictReader(open(fn)):
-            for k in ("mesh_sweep_kernel", "collide_span_kernel", "sample_kernel"):
+            for k in (("collide_span_kernel",) if allp else ("mesh_sweep_kernel", "collide_eval_kernel", "sample_kernel")):
                 if k in r["Kernel_Name"]:
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
@@ -49,4 +56,4 @@ with open(out + "/pipeline_summary.md", "w") as f:
             f.write(f"| `{k}` | {c} | {v:.6g} |\n")
 PY
 cat $OUT/pipeline_summary.md
-rm -rf $OUT/c2 $OUT/c3 $OUT/aux $OUT/pmc3 $OUT/p49
+rm -rf $OUT/c2 $OUT/c3 $OUT/c2all $OUT/aux $OUT/pmc3 $OUT/pmc3all $OUT/p49
