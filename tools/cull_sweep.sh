@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the exact broad phase of the pairwise pass: the configs[2] fixture pipeline per forced sample-part count, then
+# A/B of the exact broad phase of the pairwise pass: the configs[2] fixture pipeline per evaluator (MODES), then
 # dense (nothing can be culled) and sparse synthetic swarms with and without the broad phase.  GPU box only; output
 # under gpurun_out/.
 set -e
