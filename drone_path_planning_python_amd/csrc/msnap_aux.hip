@@ -1032,7 +1032,9 @@ __device__ __host__ __forceinline__ bool cull_use_groups(int shares, int groups,
 // blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
 constexpr int kSelThreads = 256;
 constexpr int kSelGroups = 8;      // group-pair selection: a's per workgroup
-constexpr int kSelTrips = 8;      // shares of a row block: at most kCullMaxDrones / 8 = kSelTrips * kSelThreads
+// kSelTrips (template parameter): trips of a workgroup over a row block's shares / a group's partners: 4 up to 8192
+// drones, 8 up to kCullMaxDrones (16 384 / 8 = 8 x kSelThreads)
+template <int kSelTrips>
 __global__ void __launch_bounds__(kSelThreads)
 collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt,
                       int32_t *__restrict__ meta, CullGroups cg) {
@@ -1124,6 +1126,7 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
   double cbx[kSelTrips][6], cmx[kSelTrips];
 #pragma unroll
   for (int t = 0; t < kSelTrips; ++t) {
+    if (t * kSelThreads >= nsh) continue;      // (workgroup-uniform)
     const int k = t * kSelThreads + threadIdx.x, J = I * GPB + (k < nsh ? k : nsh - 1);
 #pragma unroll
     for (int c = 0; c < 6; ++c) cbx[t][c] = cu.colbox[(size_t)J * 6 + c];
@@ -1688,7 +1691,8 @@ constexpr int kCullMaxDrones = 16384;
 constexpr int kCullMinDrones = 3072;
 constexpr int kRankWaves = 16;
 constexpr int kRankTile = 16;
-constexpr int kRankKeys = kCullMaxDrones / (kRankWaves * kWave);      // words per lane at most
+// kRankKeys (template parameter): words per lane, N / 1024 rounded up to 4, 8 or 16 (kCullMaxDrones)
+template <int kRankKeys>
 __global__ void __launch_bounds__(kWave * kRankWaves)
 collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict__ perm) {
   __shared__ int cnt[kRankWaves][kRankTile];
@@ -1697,8 +1701,11 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
   unsigned long long mine[kRankKeys];
 #pragma unroll
   for (int q = 0; q < kRankKeys; ++q) {
-    const int j = (w * nq + q) * kWave + lane;
-    mine[q] = (q < nq && j < N) ? ((unsigned long long)key[j] << 32) | (unsigned)j : ~0ull;      // (~0: below nothing)
+    mine[q] = ~0ull;      // (~0: below nothing)
+    if (q < nq) {         // (wave-uniform: a swarm of 4096 has 4 of the 16 words)
+      const int j = (w * nq + q) * kWave + lane;
+      if (j < N) mine[q] = ((unsigned long long)key[j] << 32) | (unsigned)j;
+    }
   }
   const int i0 = blockIdx.x * kRankTile;
 #pragma unroll
@@ -1707,7 +1714,8 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
     const unsigned long long ki = ((unsigned long long)key[i] << 32) | (unsigned)i;
     int c = 0;
 #pragma unroll
-    for (int q = 0; q < kRankKeys; ++q) c += __popcll(__ballot(mine[q] < ki));
+    for (int q = 0; q < kRankKeys; ++q)
+      if (q < nq) c += __popcll(__ballot(mine[q] < ki));
     if (lane == 0) cnt[w][t] = c;
   }
   __syncthreads();
@@ -1960,7 +1968,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
                        ctx->stream, pos_cols, N, n_samples, box, key, meta);
     MSNAP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(collide_rank_kernel, dim3((N + kRankTile - 1) / kRankTile), dim3(kWave * kRankWaves), 0, ctx->stream,
+    hipLaunchKernelGGL((N <= 4096 ? collide_rank_kernel<4> : N <= 8192 ? collide_rank_kernel<8> : collide_rank_kernel<16>),
+                       dim3((N + kRankTile - 1) / kRankTile), dim3(kWave * kRankWaves), 0, ctx->stream,
                        (const unsigned *)key, N, perm);
     MSNAP_HIP(ctx, hipGetLastError());
     const int ny = (E + 31) / 32;
@@ -1972,7 +1981,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                        colbox, cmax, dmin, pmin);
     MSNAP_HIP(ctx, hipGetLastError());
     CollideCull cu{colbox, cmax};
-    hipLaunchKernelGGL(collide_select_kernel, dim3(g.n_rb + (unsigned)((nJ + kSelGroups - 1) / kSelGroups)), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
+    hipLaunchKernelGGL((N <= 8192 ? collide_select_kernel<4> : collide_select_kernel<8>),
+                       dim3(g.n_rb + (unsigned)((nJ + kSelGroups - 1) / kSelGroups)), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
                        surv, cnt, meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_eval_kernel, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
