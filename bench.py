@@ -408,8 +408,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         coef, dur, status = comp.solve_grid(twp)      # the swarm shares the reference's uniform grid: K2
         mark()
         rows_t = None
-        if world == 1:      # the sampler also writes the transposed row image the pairwise pass reads
-            pos, rows_t = comp.sample_rows_t(coef, dur, synthetic.SAMPLE_DT, S)
+        if world == 1:      # the sampler also writes the transposed row image, if the pairwise pass is going to read it
+            pos, rows_t = comp.sample_rows_t(coef, dur, synthetic.SAMPLE_DT, S, n_cols=N)
         else:
             pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
         mark()

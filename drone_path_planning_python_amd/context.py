@@ -372,6 +372,12 @@ class Context:
     def collide_rows_t_doubles(self, n_rows: int, n_samples: int) -> int:
         return int(self._lib.msnap_collide_rows_t_doubles(int(n_rows), int(n_samples)))
 
+    def collide_reads_rows_t(self, n_rows: int, row_offset: int, n_cols: int, n_samples: int) -> bool:
+        """Whether formation_collide_t_device with these arguments would read a row image (msnap.h): a whole swarm
+        behind the exact broad phase builds its own, spatially sorted one."""
+        return bool(self._lib.msnap_formation_collide_reads_rows_t(self._h, int(n_rows), int(row_offset), int(n_cols),
+                                                                   int(n_samples)))
+
     def sample_collide_device(self, n_drones, n_seg, coef, dur, dt, n_samples, pos, pos_t):
         """The sampler with its second output: the transposed row image the pairwise pass reads."""
         with self._lock:

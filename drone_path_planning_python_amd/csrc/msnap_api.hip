@@ -601,6 +601,11 @@ size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples) {
   return ((size_t)n_rows + 127) / 128 * 128 * (size_t)n_samples * 3;
 }
 
+int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
+  if (!ctx || n_rows <= 0 || n_cols <= 0 || n_samples < 6) return 0;      // (paths shorter than one sample chunk: plain loops)
+  return formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples) ? 0 : 1;
+}
+
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
                                 double dt, int n_samples, double *pos, double *pos_t) {
   if (!sample_args_ok(ctx, n_drones, n_samples, 3, dt)) return MSNAP_EINVAL;

@@ -1008,7 +1008,8 @@ enum : int {
 // The second granularity of the broad phase: pairs of GROUPS (8 x 8 drones of the sorted order).  Of a surviving share
 // (128 rows x 8 columns) usually one or two of its 16 row groups are what kept it; the group pairs that pass the same
 // test are a few per cent of all (fixture: 3919 of 131 328, 0.25 M pairs against the surviving shares' 1.43 M).  They
-// are evaluated by collide_group_kernel with the samples across the lanes; the minima meet in per-drone atomics.
+// are evaluated by collide_eval_kernel (collide_group_body) with the samples across the lanes; the minima meet in
+// per-drone atomics.
 struct CullGroups {
   int32_t *glist;                 // [cap] (a << 16 | b), a <= b: surviving group pairs, any order
   unsigned long long *dmin;       // [N] bit pattern of the smallest squared distance so far (sorted index)
@@ -1476,7 +1477,7 @@ collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restri
     }
   };
   if (cnt) {
-    // broad-phase pass (collide_span_list_kernel): the row block's surviving shares are consecutive entries
+    // broad-phase pass through the surviving shares (collide_span_list_body): they are consecutive entries per row block
     const int I = __builtin_amdgcn_readfirstlane(r / kRowBlock);      // (kMergeRows divides kRowBlock)
     CullSplit sp;
     sp.lo = meta[kMetaParts];
@@ -1827,6 +1828,14 @@ collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, co
   }
 }
 
+// whether a pass with these arguments runs behind the exact broad phase (which builds its own, spatially sorted, row
+// image: a caller-provided one is then not read -- msnap_formation_collide_reads_rows_t)
+bool formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
+  if (n_samples < kSampleChunk || n_rows != n_cols || row_offset != 0 || ctx->collide_no_cull || ctx->collide_no_sym) return false;
+  const int cull_min = ctx->collide_cull_min_drones > 0 ? ctx->collide_cull_min_drones : kCullMinDrones;
+  return n_rows >= cull_min && n_rows >= 2 * kRowBlock && n_rows <= kCullMaxDrones;
+}
+
 // `rows_t`: the rows' transposed image [n_samples][3][row pitch] when the caller already has it (the sampler's
 // second output, msnap_sample_collide); nullptr: built here from pos_rows
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
@@ -1922,9 +1931,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // (below some 3000 drones the six small launches in front of the pass cost more than a sparse swarm saves:
   // 2048 x 91 dense 91 -> 121 us, sparse 92 -> 84; 4096 x 91 dense 243 -> 282, sparse 243 -> 122, the formation
   // fixture 243 -> 105)
-  const int cull_min = ctx->collide_cull_min_drones > 0 ? ctx->collide_cull_min_drones : kCullMinDrones;
-  const bool cull = g.sym && row_offset == 0 && n_rows == n_cols && !ctx->collide_no_cull && n_rows >= cull_min &&
-                    n_rows >= 2 * kRowBlock && n_rows <= kCullMaxDrones;
+  const bool cull = g.sym && formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples);
   ctx->collide_last_cull = cull ? 1 : 0;
   ctx->collide_last_shares = (int)(waves < 0x7fffffff ? waves : 0x7fffffff);
   const int E = n_samples * 3;

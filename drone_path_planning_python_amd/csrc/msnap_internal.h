@@ -126,6 +126,7 @@ int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef
 int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples,
                              const double *pos_rows, const double *pos_cols, double radius,
                              double *min_dist, int32_t *partner, int32_t *hit, const double *rows_t);
+bool formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples);
 int launch_formation_collide_part(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all, int part,
                                   int n_parts, double *out_d2, int32_t *out_j);
 int launch_formation_collide_finish(msnap_ctx *ctx, int n_drones, int n_parts, const void *parts, size_t part_stride,

@@ -101,11 +101,16 @@ class DeviceCompute:
             self.ctx.sample_device(n, M, coef, dur, dt, n_samples, 3, pos)
         return pos
 
-    def sample_rows_t(self, coef, dur, dt, n_samples):
+    def sample_rows_t(self, coef, dur, dt, n_samples, n_cols=None):
         """(pos [n, S, 3], pos_t): the sampler's second output is the transposed row image [S][3][pitch] the
-        pairwise pass reads -- `collide(..., rows_t=pos_t)` then skips its own transposition pass."""
+        pairwise pass reads -- `collide(..., rows_t=pos_t)` then skips its own transposition pass.  With `n_cols`
+        (the columns these rows, as a shard at offset 0, will meet) the library is asked first whether that pass would
+        read the image at all -- a whole swarm behind the exact broad phase sorts itself spatially and builds its own --
+        and pos_t is None if not."""
         torch = self.torch
         n, M = dur.shape
+        if n_cols is not None and not self.ctx.collide_reads_rows_t(n, 0, n_cols, n_samples):
+            return self.sample(coef, dur, dt, n_samples), None
         pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
         pos_t = torch.empty((self.ctx.collide_rows_t_doubles(n, n_samples),), dtype=torch.float64, device=self.device)
         if n:
@@ -262,7 +267,7 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
                          f"[{lo}, {hi}); their samples are NaN and cannot be collision-checked")
     rows_t = None
     if world == 1 and hasattr(compute, "sample_rows_t"):
-        pos_local, rows_t = compute.sample_rows_t(coef_local, dur_local, dt, n_samples)
+        pos_local, rows_t = compute.sample_rows_t(coef_local, dur_local, dt, n_samples, n_cols=n_total)
     else:
         pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
     overlapped = mesh_tris is not None and hasattr(compute, "mesh_begin")

@@ -260,6 +260,10 @@ int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, i
  * transposition pass over pos_rows.  Device pointers only: the pair exists to keep the formation pipeline
  * (sampler -> pairwise pass) on the GPU without the intermediate pass. */
 size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples);
+/* 1 if msnap_formation_collide_t_device with these arguments would read the row image, 0 if not -- a whole swarm
+ * behind the exact broad phase ("collide_no_cull") is sorted spatially first and builds its own, and paths shorter
+ * than 6 samples take plain loops: the caller can then sample with msnap_sample and save the second output. */
+int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples);
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
                                 const double *dur, double dt, int n_samples, double *pos, double *pos_t);
 int msnap_formation_collide_t_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,

@@ -19,6 +19,7 @@ int launch_snap_cost(msnap_ctx *, int, int, const double *, const double *, doub
 int launch_formation_collide(msnap_ctx *, int, int, int, int, const double *, const double *, double, double *, int32_t *,
                              int32_t *, const double *) { return unreachable(); }
 int launch_formation_collide_part(msnap_ctx *, int, int, const double *, int, int, double *, int32_t *) { return unreachable(); }
+bool formation_collide_takes_broad_phase(const msnap_ctx *, int, int, int, int) { return false; }
 int launch_formation_collide_finish(msnap_ctx *, int, int, const void *, size_t, int, int, double, double *, int32_t *,
                                     int32_t *) { return unreachable(); }
 int launch_mesh_sweep(msnap_ctx *, int, int, const double *, int, const double *, double, double *, int32_t *) { return unreachable(); }
