@@ -2276,17 +2276,33 @@ mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__
     for (int t0 = 0; t0 < n_tris; t0 += kWave) {
       const int tl = t0 + lane;
       double lb = (tl < n_tris) ? box_tri_lb2(lo, hi, tris + (size_t)(tl < n_tris ? tl : 0) * 9) : INFINITY;
-      for (;;) {
-        const double m = uniform_f64(wave_min_f64(lb));
-        if (!(m < wbest)) break;                               // also ends the group when every bound is spent (inf)
-        const unsigned long long holders = __ballot(lb == m);
-        const int sel = __builtin_ctzll(holders);              // wave-uniform: the ballot is a scalar
+      // the triangle with the smallest bound first: it usually sets the distance the others have to beat
+      const double m = uniform_f64(wave_min_f64(lb));
+      if (!(m < wbest)) continue;                              // (also when the group has no triangle: every bound inf)
+      {
+        const int sel = __builtin_ctzll(__ballot(lb == m));    // wave-uniform: the ballot is a scalar
         lb = (lane == sel) ? INFINITY : lb;
         const double v = pt_tri_d2(px, py, pz, tris + (size_t)(t0 + sel) * 9);
         best = (v < best) ? v : best;
         wbest = uniform_f64(wave_min_f64(best));
         done += 1;
       }
+      // then every triangle whose bound is still below the best distance, in lane order; the best distance (two
+      // cross-lane reductions: as long as a third of a triangle's evaluation) is refreshed every fourth triangle only --
+      // a superset of what the one-by-one order evaluates, the same minimum
+      unsigned long long cand = __ballot(lb < wbest);
+      for (int k = 1; cand; ++k) {
+        const int sel = __builtin_ctzll(cand);
+        cand &= cand - 1;
+        const double v = pt_tri_d2(px, py, pz, tris + (size_t)(t0 + sel) * 9);
+        best = (v < best) ? v : best;
+        done += 1;
+        if ((k & 3) == 0 && cand) {
+          wbest = uniform_f64(wave_min_f64(best));
+          cand &= __ballot(lb < wbest);
+        }
+      }
+      wbest = uniform_f64(wave_min_f64(best));
     }
   }
   best = wave_min_f64(best);
