@@ -318,3 +318,49 @@ def test_row_image_query_follows_the_broad_phase(ctx7):
         assert rows_t2 is not None and torch.equal(pos[:1000], pos2)
     finally:
         comp.close()
+
+
+@pytest.mark.gpu
+def test_broad_phase_pass_replays_from_a_graph():
+    """The whole-swarm pass behind its broad phase is plain stream work -- counters zeroed by its first kernel, lists and
+    per-drone atomics rebuilt per pass, no host read-back: captured into a graph (after one eager call has sized the
+    context's buffers) it replays with new positions in the same buffers and gives the eager results."""
+    import torch
+    from drone_path_planning_python_amd import Context
+    rng = np.random.default_rng(99)
+    n, S = 3072, 19
+    dev = torch.device("cuda", 0)
+    pos_a = torch.from_numpy(_broad_phase_swarm("teams", n, S, rng)).to(dev)
+    pos_b = torch.from_numpy(_broad_phase_swarm("sparse", n, S, rng)).to(dev)
+    buf = pos_a.clone()
+    md = torch.empty((n,), dtype=torch.float64, device=dev)
+    partner = torch.empty((n,), dtype=torch.int32, device=dev)
+    hit = torch.empty((n,), dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    with Context(order=7, max_segments=16) as ctx:
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            eager = {}
+            for name, p in (("a", pos_a), ("b", pos_b)):
+                buf.copy_(p)
+                ctx.formation_collide_device(n, 0, n, S, buf, buf, 0.3, md, partner, hit)
+                assert ctx.get_option("collide_last_cull") == 1
+                side.synchronize()
+                eager[name] = (md.clone(), partner.clone(), hit.clone())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                ctx.formation_collide_device(n, 0, n, S, buf, buf, 0.3, md, partner, hit)
+            ctx.set_stream(side.cuda_stream)
+            for name, p in (("a", pos_a), ("b", pos_b), ("a", pos_a)):
+                buf.copy_(p)
+                md.zero_()
+                partner.zero_()
+                g.replay()
+                side.synchronize()
+                for got, want in zip((md, partner, hit), eager[name]):
+                    assert torch.equal(got, want)
+        ctx.use_own_stream()
+    ref = c_oracle.formation_collide(pos_b.cpu().numpy(), 0.3)
+    np.testing.assert_array_equal(eager["b"][0].cpu().numpy(), ref[0])
+    np.testing.assert_array_equal(eager["b"][1].cpu().numpy(), ref[1])
