@@ -27,9 +27,11 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                      env-scene-ltu-experiment.stl
                  [4] 65536 x 10, order 9 (its launches under a hipGraph, like the headline's)
                For N > 1 configs [2]-[4] are SHARDED by drone over the ranks (strong scaling): the
-               formation pass becomes sample -> RCCL all-gather of the positions -> this rank's PART of
-               the swarm's unordered pairs (every pair on exactly one rank) -> all-gather of the
-               12-byte-per-drone partial minima -> fold, both collectives inside the timed region.
+               formation pass becomes sample -> RCCL all-gather of the positions -> either this rank's PART
+               of the swarm's unordered pairs (every pair on exactly one rank) -> all-gather of the
+               12-byte-per-drone partial minima -> fold, or -- where the exact broad phase leaves so few
+               pairs that a rank is quicker alone -- the pass over the whole gathered swarm on every rank;
+               the collectives are inside the timed region.
                [2]/[3] run on the formation-like inputs pinned by tests/golden/formation_golden.npz
                and report their hit counts beside the fixture's.
   strong_scaling  total work fixed and sharded over the ranks (what a SCALE curve over N should be read
@@ -389,10 +391,19 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     comp = swarm.DeviceCompute(ctx, torch, side_ctx=side_ctx)
     twp = torch.from_numpy(np.ascontiguousarray(wp[lo:hi])).to(device)
     tt = torch.from_numpy(t).to(device)
-    stage_names = ["solve", "sample"] + (["allgather", "pairwise", "allgather_parts", "fold"] if world > 1 else ["pairwise"]) + \
-        (["mesh"] if cfg == 3 else [])
-    nst = len(stage_names)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
+    # several ranks: "parts" (every pair on exactly one rank, second all-gather, fold) or "whole" (every rank the whole
+    # gathered swarm behind the broad phase, no second collective) -- swarm.DeviceCompute.pairwise_mode decides from the
+    # survivor counts of a first whole pass, here in an untimed probe pipeline below
+    mode = {"pairwise": "parts"}
+    stage_names, nst, ev = [], 0, []
+
+    def set_stages():
+        nonlocal stage_names, nst, ev
+        multi = (["allgather", "pairwise"] if mode["pairwise"] == "whole" else ["allgather", "pairwise", "allgather_parts", "fold"])
+        stage_names = ["solve", "sample"] + (multi if world > 1 else ["pairwise"]) + (["mesh"] if cfg == 3 else [])
+        nst = len(stage_names)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
+    set_stages()
 
     def one(rec, overlap):
         """one pipeline; `overlap`: the mesh sweep on the side stream next to the exchange and the pairwise
@@ -416,7 +427,11 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         try:
             if tris is not None and overlap:
                 comp.mesh_begin(pos, tris, synthetic.DRONE_RADIUS)
-            if world > 1:
+            if world > 1 and mode["pairwise"] == "whole":
+                pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch)
+                mark()
+                md, partner, hit = (x[lo:hi] for x in comp.collide(pos_all, 0, pos_all, synthetic.DRONE_RADIUS))
+            elif world > 1:
                 pos_all = swarm.all_gather_positions(pos, N, world, rank, coll, torch)
                 mark()
                 part = comp.collide_part(pos_all, rank, world)        # this rank's share of the swarm's pairs
@@ -452,6 +467,14 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         return w, out
 
     ctx.prepare_grid(t)      # the grid's operator, once per grid (untimed, like the context itself)
+    if world > 1 and comp.pairwise_mode(N, S, world) == "whole":
+        # probe (untimed): one pipeline with the whole-swarm pass, then its survivor counts decide (same on every rank)
+        mode["pairwise"] = "whole"
+        set_stages()
+        one(None, False)
+        comp.note_whole_pass(N, S, world)
+        mode["pairwise"] = comp.pairwise_mode(N, S, world)
+        set_stages()
     # pass 1, stream order: per-stage times (events between the stages)
     wall, (status, hit, mh, md, pos_keep) = timed(False, ev)
     grid_kernel = ctx.last_kernel()     # what the library launched for the shared-grid solve (msnap_last_kernel)
@@ -472,9 +495,10 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     torch.cuda.synchronize()
     gemm_us = e0.elapsed_time(e1) / reps * 1e3
     k1_kernel = ctx.last_kernel()
-    pair_once = bool(ctx.get_option("collide_last_sym")) if world == 1 else True   # (parts: by construction)
-    # one rank, a whole swarm of 3072..16384 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
-    broad = bool(ctx.get_option("collide_last_cull")) if world == 1 else False
+    whole = world > 1 and mode["pairwise"] == "whole"      # every rank the whole gathered swarm behind the broad phase
+    pair_once = bool(ctx.get_option("collide_last_sym")) if world == 1 else not whole   # (parts: by construction)
+    # a whole swarm of 3072..16384 drones: the pass runs behind its exact broad phase (msnap.h "collide_no_cull")
+    broad = bool(ctx.get_option("collide_last_cull")) if (world == 1 or whole) else False
     shares, survivors = (ctx.get_option("collide_last_shares"), ctx.get_option("collide_last_survivors")) if broad else (0, 0)
     group_pairs = ctx.get_option("collide_last_group_pairs") if broad else 0
     # the library's own rule (csrc/msnap_aux.hip::cull_use_groups): 8 x 8 group pairs when they are few against the shares
@@ -510,7 +534,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                     f"{off.shape[0]} offsets through a8) on the reference's uniform grid, {S} samples at dt = "
                     f"{synthetic.SAMPLE_DT} s" + (f", {tris.shape[0]}-triangle scene (env-scene-hole.stl + "
                                                    f"env-scene-ltu-experiment.stl)" if tris is not None else ""),
-        "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling)", "rccl_ranks": world,
+        "sharding": f"{world} rank(s) x {n_max} drones (by drone, strong scaling" +
+                    ("; the pairwise pass on the whole gathered swarm on every rank" if whole else "") + ")", "rccl_ranks": world,
         "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": st,
         "stage_us_note": "stages timed in stream order (events between them); us_per_pipeline from a second pass without them" + (
@@ -536,8 +561,13 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                       "on the surviving ") + ("8 x 8 group pairs)" if by_groups else "128 x 8 shares)")
                                      if broad else
                                      "msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)")
-                                    if world == 1 else "msnap::collide_transpose_kernel + collide_span_kernel + "
+                                    if (world == 1 or whole) else "msnap::collide_transpose_kernel + collide_span_kernel + "
                                     "collide_merge_kernel on this rank's part of the swarm's pairs"),
+                         "ranks": (None if world == 1 else
+                                   "every rank runs the pass over the whole gathered swarm behind the broad phase and keeps "
+                                   "its rows: no second collective (swarm.DeviceCompute.pairwise_mode, decided from the "
+                                   "survivor counts of an untimed probe pass)" if whole else
+                                   "every unordered pair on exactly one rank, second all-gather of the partial minima, fold"),
                          "bound": "valu_f64", "pairs_evaluated_once_over_all_ranks": pair_once,
                          "broad_phase": ({"shares": shares, "shares_surviving": survivors,
                                           "group_pairs": (N // 8) * (N // 8 + 1) // 2, "group_pairs_surviving": group_pairs,
@@ -565,11 +595,12 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         rep["stages"]["allgather"] = {
             "collective": coll_name, "bound": "xgmi", "bytes_received_per_rank": (N - n_max) * S * 24,
             "frac": (N - n_max) * S * 24 / (st["allgather"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
-        rep["stages"]["allgather_parts"] = {
-            "collective": coll_name, "bound": "xgmi (latency)", "bytes_received_per_rank": (world - 1) * pb,
-            "what": "per-drone partial minima of every rank's part: 12 bytes per drone and rank",
-            "frac": (world - 1) * pb / (st["allgather_parts"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
-        rep["stages"]["fold"] = {"kernel": "msnap::collide_finish_kernel", "bound": "latency"}
+        if not whole:
+            rep["stages"]["allgather_parts"] = {
+                "collective": coll_name, "bound": "xgmi (latency)", "bytes_received_per_rank": (world - 1) * pb,
+                "what": "per-drone partial minima of every rank's part: 12 bytes per drone and rank",
+                "frac": (world - 1) * pb / (st["allgather_parts"] * 1e-6) / 1e9 / (7 * XGMI_LINK_GBS)}
+            rep["stages"]["fold"] = {"kernel": "msnap::collide_finish_kernel", "bound": "latency"}
     if cfg == 3:
         rep["mesh_hits"] = cnt[2]
         rep["mesh_hits_fixture"] = int(fix["cfg3_mesh_hit_idx"].size) if fix is not None else None
@@ -727,11 +758,14 @@ def main():
                             "us_per_pipeline": c["us_per_pipeline"], "stage_us": c["stage_us"]}
                 strong = {"n_gpus": world,
                           "note": "total work fixed and sharded by drone over the ranks; value = drones / max-over-ranks time; "
-                                  "the formation pipelines include both collectives of the pairwise pass.  One GPU runs a "
+                                  "the formation pipelines include the collectives of the pairwise pass.  One GPU runs a "
                                   "whole swarm of 3072..16384 drones behind the exact broad phase of the pairwise pass "
-                                  "(formation_4096x10); the sharded pass evaluates every pair, 1 / n_gpus of them per rank, "
-                                  "so its curve starts from formation_4096x10_all_pairs -- and at 4096 drones one GPU "
-                                  "behind the broad phase is faster than two or four ranks with their two collectives",
+                                  "(formation_4096x10; formation_4096x10_all_pairs is the same pipeline with it off).  "
+                                  "Several ranks shard the solve and the sampler and then either divide the pairs (every "
+                                  "pair on exactly one rank, a second all-gather, a fold) or -- where the broad phase "
+                                  "leaves so few pairs that one GPU is quicker alone -- each run the whole gathered swarm "
+                                  "and keep their rows (`sharding` says which): for these formation swarms the pairwise "
+                                  "stage then no longer scales, it is 68 us on any number of ranks",
                           "solve_order9_65536x10": brief(c4), "solve_order7_65536x10": brief(s7),
                           "formation_4096x10": brief(c2), "formation_16384x10": brief(big)}
                 if c2_all is not None:

@@ -64,6 +64,7 @@ class DeviceCompute:
             side_ctx.use_own_stream()
             self.side = torch_module.cuda.ExternalStream(side_ctx.stream(), device=self.device)
         self._mesh_pending = None
+        self._whole_ok = {}      # (n_total, n_samples, world) -> the broad-phase pass over the whole swarm pays (pairwise_mode)
 
     def solve(self, wp, t):
         torch = self.torch
@@ -130,6 +131,37 @@ class DeviceCompute:
             self.ctx.formation_collide_device(r, row_offset, pos_all.shape[0], pos_rows.shape[1], pos_rows,
                                               pos_all, radius, md, partner, hit)
         return md, partner, hit
+
+    # ---- several ranks: who evaluates which pairs -------------------------------------------------------------
+    # "parts": every unordered pair on exactly one rank (collide_part), a second small all-gather, the fold -- the
+    # arithmetic is divided by the number of ranks.  "whole": every rank runs the pass over the WHOLE gathered swarm
+    # behind the exact broad phase and keeps its rows -- no second collective, and on swarms where the broad phase culls
+    # (4096-drone formation fixture: 3 % of the pairs are evaluated, 68 us) that is less than a rank's part of all pairs
+    # plus its collective.  The choice is made from the survivor counts of the first whole pass (one stream
+    # synchronisation, once per swarm shape): identical on every rank, since every rank ran it on the same positions.
+    def pairwise_mode(self, n_total, n_samples, world):
+        key = (int(n_total), int(n_samples), int(world))
+        if world == 1 or self._whole_ok.get(key) is False:
+            return "parts"
+        # would the library run the whole-swarm pass behind the broad phase at all? (size limits, "collide_no_cull")
+        return "whole" if not self.ctx.collide_reads_rows_t(n_total, 0, n_total, n_samples) and n_samples >= 6 else "parts"
+
+    def note_whole_pass(self, n_total, n_samples, world):
+        """After a whole-swarm pass: decide once whether it pays against the parts (reads the pass's survivor counts)."""
+        key = (int(n_total), int(n_samples), int(world))
+        if key in self._whole_ok:
+            return
+        if not self.ctx.get_option("collide_last_cull"):
+            self._whole_ok[key] = False
+            return
+        shares, surv = self.ctx.get_option("collide_last_shares"), self.ctx.get_option("collide_last_survivors")
+        groups = self.ctx.get_option("collide_last_group_pairs")
+        by_groups = groups <= (1 << 18) and groups * 141 < surv * 1485          # csrc/msnap_aux.hip::cull_use_groups
+        evaluated = groups * 64.0 if by_groups else surv * 1024.0
+        ratio = evaluated / max(1.0, n_total * (n_total - 1) / 2.0)
+        # whole: the small launches (~45 us at 4096 drones) + ratio x 1.5 of the all-pairs time; parts: 1 / world of it
+        # + transposition, merge, fold and the second collective (~45 us)
+        self._whole_ok[key] = ratio * 1.5 * world < 1.0
 
     def collide_part(self, pos_all, part, n_parts):
         """This rank's part of the pass over the whole swarm: uint8 [formation_part_bytes(N)] (squared minima
@@ -276,9 +308,14 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
     try:
         if world > 1:
             pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch)
-            part = compute.collide_part(pos_all, rank, world)
-            parts = all_gather_parts(part, world, dist, torch)
-            md, partner, hit = compute.collide_finish(parts, n_total, lo, hi - lo, radius)
+            mode = compute.pairwise_mode(n_total, n_samples, world) if hasattr(compute, "pairwise_mode") else "parts"
+            if mode == "whole":
+                md, partner, hit = (x[lo:hi] for x in compute.collide(pos_all, 0, pos_all, radius))
+                compute.note_whole_pass(n_total, n_samples, world)
+            else:
+                part = compute.collide_part(pos_all, rank, world)
+                parts = all_gather_parts(part, world, dist, torch)
+                md, partner, hit = compute.collide_finish(parts, n_total, lo, hi - lo, radius)
         else:
             pos_all = pos_local
             if rows_t is not None:

@@ -364,3 +364,31 @@ def test_broad_phase_pass_replays_from_a_graph():
     ref = c_oracle.formation_collide(pos_b.cpu().numpy(), 0.3)
     np.testing.assert_array_equal(eager["b"][0].cpu().numpy(), ref[0])
     np.testing.assert_array_equal(eager["b"][1].cpu().numpy(), ref[1])
+
+
+@pytest.mark.gpu
+def test_multi_rank_pairwise_mode_follows_the_survivor_counts(ctx7):
+    """swarm.DeviceCompute.pairwise_mode: several ranks run the whole gathered swarm behind the broad phase where it
+    culls, and fall back to the parts (every pair on one rank) where it does not -- decided once per swarm shape from
+    the survivor counts of the first whole pass, hence identically on every rank."""
+    import torch
+    from drone_path_planning_python_amd import swarm as sw
+    rng = np.random.default_rng(3)
+    comp = sw.DeviceCompute(ctx7, torch)
+    try:
+        assert comp.pairwise_mode(4096, 91, 1) == "parts"                 # one rank: not a question
+        assert comp.pairwise_mode(1024, 91, 4) == "parts"                 # too small for the broad phase
+        n, S = 3072, 12
+        assert comp.pairwise_mode(n, S, 4) == "whole"
+        sparse = torch.from_numpy(_broad_phase_swarm("sparse", n, S, rng)).cuda()
+        comp.collide(sparse, 0, sparse, 0.3)
+        comp.note_whole_pass(n, S, 4)
+        assert comp.pairwise_mode(n, S, 4) == "whole"
+        dense = torch.from_numpy(_broad_phase_swarm("dense", n, S + 1, rng)).cuda()
+        assert comp.pairwise_mode(n, S + 1, 4) == "whole"
+        comp.collide(dense, 0, dense, 0.3)
+        comp.note_whole_pass(n, S + 1, 4)
+        assert comp.pairwise_mode(n, S + 1, 4) == "parts"                 # nothing culled: divide the pairs instead
+        assert comp.pairwise_mode(n, S, 4) == "whole"                     # (per swarm shape)
+    finally:
+        comp.close()
