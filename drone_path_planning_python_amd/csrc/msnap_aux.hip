@@ -970,12 +970,16 @@ struct CullSplit {
 __device__ __host__ __forceinline__ CullSplit cull_split(int tot, int slots, int nch, int force) {
   CullSplit c;
   c.x = 0;
-  const int maxp = (force >> 8) > 0 && (force >> 8) < kCullMaxParts ? (force >> 8) : kCullMaxParts;
+  int maxp = (force >> 8) > 0 && (force >> 8) < kCullMaxParts ? (force >> 8) : kCullMaxParts;
   force &= 0xff;
   if (force > 0) {
     c.lo = c.hi = force < maxp ? force : maxp;
     return c;
   }
+  // the row-side entries of a launch are laid out for max(shares, 2 x slots) items (launch_formation_collide): a share
+  // is cut only while the items stay below twice the wave slots
+  const int fit = tot > 0 ? 2 * slots / tot : maxp;
+  maxp = fit < maxp ? (fit > 1 ? fit : 1) : maxp;
   const int simds = slots / 4 > 0 ? slots / 4 : 1;
   int best = 1;
   long long best_cost = -1;
@@ -1947,8 +1951,8 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     ctx->collide_last_shares = (int)shares;
     const int sp_force = (ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0) |
                          (spmax << 8);
-    // row-side entries: one per item; cull_split cuts shares only to fill the wave slots once
-    const long long items_max = (sp_force & 0xff) ? shares * (sp_force & 0xff) : (shares > slots ? shares : slots);
+    // row-side entries: one per item; cull_split cuts shares only while the items stay below twice the wave slots
+    const long long items_max = (sp_force & 0xff) ? shares * (sp_force & 0xff) : (shares > 2 * slots ? shares : 2 * slots);
     const size_t entries = (size_t)items_max * kRowBlock;
     const size_t centries = (size_t)g.n_rb * spmax * N;
     // group-pair path (CullGroups): list, candidate slots (16 per item), per-drone atomics

@@ -227,7 +227,8 @@ def _broad_phase_swarm(kind, n, S, rng):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,S", [("dense", 300, 19), ("sparse", 256, 91), ("sparse", 1000, 37), ("sparse", 2049, 13),
                                       ("teams", 777, 24), ("teams", 1536, 91), ("far", 600, 30), ("sparse", 513, 6),
-                                      ("teams", 3072, 12), ("sparse", 9001, 7), ("teams", 16384, 6)])
+                                      ("teams", 3072, 12), ("sparse", 9001, 7), ("teams", 16384, 6),
+                                      ("dense", 2049, 38)])      # (2193 shares in 2 parts each: more items than wave slots)
 def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
     """The whole-swarm pass behind its exact broad phase (spatial sort, per-drone bounds, box test per 8-column share,
     surviving shares only): distances, partners and hits bit for bit those of the oracle's all-pairs pass -- with failed
@@ -392,3 +393,16 @@ def test_multi_rank_pairwise_mode_follows_the_survivor_counts(ctx7):
         assert comp.pairwise_mode(n, S, 4) == "whole"                     # (per swarm shape)
     finally:
         comp.close()
+
+
+@pytest.mark.gpu
+def test_broad_phase_on_random_shapes():
+    """tools/cull_stress.py, 60 seeded cases: random swarm sizes (also one short of and one past the tile sizes), sample
+    counts, kinds, NaN drones and samples, coincident drones, every evaluator and forced sample parts -- each equal to
+    the oracle.  (The tool found the shape of ("dense", 2049, 38) above: shares cut into more items than the row-side
+    entries were laid out for.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cull_stress", os.path.join(os.path.dirname(GOLDEN_DIR), "..", "tools", "cull_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(budget=120.0, seed=5, max_cases=60, big=False) == 60
