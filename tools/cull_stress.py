@@ -16,7 +16,7 @@ from drone_path_planning_python_amd import Context  # noqa: E402
 from test_formation_full import _broad_phase_swarm  # noqa: E402
 
 
-def run(budget=60.0, seed=1, max_cases=None, big=True):
+def run(budget=60.0, seed=1, max_cases=None, big=True, others=True):
     rng = np.random.default_rng(seed)
     edges = [256, 257, 511, 512, 513, 1023, 1025, 2047, 2049, 3071, 3073, 4095, 4097, 6145, 8191, 8193]
     t0, n_cases = time.time(), 0
@@ -39,15 +39,34 @@ def run(budget=60.0, seed=1, max_cases=None, big=True):
             parts = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))
             ctx.set_option("collide_cull_mode", mode)
             ctx.set_option("collide_sample_parts", parts)
-            got = ctx.formation_collide(pos, pos, 0.3)
-            assert ctx.get_option("collide_last_cull") == 1
             ref = c_oracle.formation_collide(pos, 0.3)
+            # the other ways through the pass, now and then: broad phase off, a shard of the rows, the pass in parts
+            way = str(rng.choice(["whole", "whole", "whole", "plain", "shard", "parts"])) if others else "whole"
+            if way == "plain":
+                ctx.set_option("collide_no_cull", 1)
+                got = ctx.formation_collide(pos, pos, 0.3)
+                ctx.set_option("collide_no_cull", 0)
+                assert ctx.get_option("collide_last_cull") == 0
+            elif way == "shard":
+                lo = int(rng.integers(0, n - 1))
+                cnt = int(rng.integers(1, n - lo + 1))
+                got = ctx.formation_collide(pos[lo:lo + cnt], pos, 0.3, row_offset=lo)
+                ref = tuple(x[lo:lo + cnt] for x in ref)
+            elif way == "parts":
+                P = int(rng.integers(2, 10))
+                ctx.set_option("collide_sample_parts", int(rng.choice([0, 0, 4])))
+                blocks = np.stack([ctx.formation_collide_part(pos, q, P) for q in range(P)])
+                got = ctx.formation_collide_finish(blocks, n, 0.3)
+            else:
+                got = ctx.formation_collide(pos, pos, 0.3)
+                assert ctx.get_option("collide_last_cull") == 1
+            mode = f"{mode} way={way}"
             for a, b, what in zip(got, ref, ("min_dist", "partner", "hit")):
                 if not np.array_equal(a, b):
                     bad = np.nonzero(~((a == b) | (np.isnan(a) & np.isnan(b))))[0][:5]
                     print(f"MISMATCH {what}: n={n} S={S} kind={kind} mode={mode} parts={parts} rows {bad} got {a[bad]} want {b[bad]}")
                     print("nan drones", np.nonzero(np.isnan(pos).all(axis=(1, 2)))[0], "bad rows total", int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum()))
-                    for m2 in (0, 1, 2):
+                    for m2 in ((0, 1, 2) if "whole" in str(mode) else ()):
                         for p2 in (0, 1, 2, 3, 5, 8):
                             ctx.set_option("collide_cull_mode", m2)
                             ctx.set_option("collide_sample_parts", p2)
