@@ -472,7 +472,7 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         mode["pairwise"] = "whole"
         set_stages()
         one(None, False)
-        comp.note_whole_pass(N, S, world)
+        comp.note_whole_pass(N, S, world, dist if use_pg else None)      # (the ranks agree: one MIN all-reduce)
         mode["pairwise"] = comp.pairwise_mode(N, S, world)
         set_stages()
     # pass 1, stream order: per-stage times (events between the stages)

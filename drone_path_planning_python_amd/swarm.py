@@ -146,14 +146,24 @@ class DeviceCompute:
         # would the library run the whole-swarm pass behind the broad phase at all? (size limits, "collide_no_cull")
         return "whole" if not self.ctx.collide_reads_rows_t(n_total, 0, n_total, n_samples) and n_samples >= 6 else "parts"
 
-    def note_whole_pass(self, n_total, n_samples, world):
-        """After a whole-swarm pass: decide once whether it pays against the parts (reads the pass's survivor counts)."""
+    def note_whole_pass(self, n_total, n_samples, world, dist=None):
+        """After a whole-swarm pass: decide once whether it pays against the parts (reads the pass's survivor counts).
+        With `dist` the ranks take the decision together (a MIN all-reduce of one flag, once per swarm shape): they all
+        ran the pass on the same positions and get the same counts, but a split decision would leave them in
+        different collectives."""
         key = (int(n_total), int(n_samples), int(world))
         if key in self._whole_ok:
             return
+        self._whole_ok[key] = self._whole_pays(n_total, world)
+        if dist is not None and world > 1:
+            flag = self.torch.tensor([1 if self._whole_ok[key] else 0], dtype=self.torch.int32,
+                                     device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            self._whole_ok[key] = bool(int(flag.item()))
+
+    def _whole_pays(self, n_total, world):
         if not self.ctx.get_option("collide_last_cull"):
-            self._whole_ok[key] = False
-            return
+            return False
         shares, surv = self.ctx.get_option("collide_last_shares"), self.ctx.get_option("collide_last_survivors")
         groups = self.ctx.get_option("collide_last_group_pairs")
         by_groups = groups <= (1 << 18) and groups * 141 < surv * 1485          # csrc/msnap_aux.hip::cull_use_groups
@@ -161,7 +171,7 @@ class DeviceCompute:
         ratio = evaluated / max(1.0, n_total * (n_total - 1) / 2.0)
         # whole: the small launches (~45 us at 4096 drones) + ratio x 1.5 of the all-pairs time; parts: 1 / world of it
         # + transposition, merge, fold and the second collective (~45 us)
-        self._whole_ok[key] = ratio * 1.5 * world < 1.0
+        return ratio * 1.5 * world < 1.0
 
     def collide_part(self, pos_all, part, n_parts):
         """This rank's part of the pass over the whole swarm: uint8 [formation_part_bytes(N)] (squared minima
@@ -311,7 +321,7 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
             mode = compute.pairwise_mode(n_total, n_samples, world) if hasattr(compute, "pairwise_mode") else "parts"
             if mode == "whole":
                 md, partner, hit = (x[lo:hi] for x in compute.collide(pos_all, 0, pos_all, radius))
-                compute.note_whole_pass(n_total, n_samples, world)
+                compute.note_whole_pass(n_total, n_samples, world, dist if hasattr(dist, "get_backend") else None)
             else:
                 part = compute.collide_part(pos_all, rank, world)
                 parts = all_gather_parts(part, world, dist, torch)

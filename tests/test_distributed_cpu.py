@@ -93,7 +93,8 @@ class WholeSwarmCompute(OracleCompute):
     def pairwise_mode(self, n_total, n_samples, world):
         return "whole"
 
-    def note_whole_pass(self, n_total, n_samples, world):
+    def note_whole_pass(self, n_total, n_samples, world, dist=None):
+        assert dist is not None and dist.get_backend() == "gloo"      # the ranks decide together
         self.noted += 1
 
     def collide_part(self, *a):
