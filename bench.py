@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Both forms give N ranks, one process per GPU.  Started plainly with `--gpus N`, N > 1 (no RANK / WORLD_SIZE in the
+environment), this process starts the second form as a child BEFORE anything here touches HIP, relays rank 0's
+JSON line and exits with the child's code.  `--gpus N` with a WORLD_SIZE that is not N, or with fewer than N GPUs
+visible to the nccl backend, exits non-zero instead of printing a line for a job that is not the one asked for.
+
 Headline (`value`, `roofline`): a "step" is one pass of the hot path (libmsnap's solve kernel, K1)
 over one batch of synthetic input: BASELINE.json configs[1], 256 drones x 10 segments, order 7,
 seeded random waypoints, per-drone random time grids (the general case: nothing is shared or
@@ -129,7 +134,12 @@ def pmc_counter(kernel: str, counter: str):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE if a launcher set it, else 1); without a "
+                         "launcher environment N > 1 starts the N ranks itself")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only bring the ranks up: process group, one all-reduce, a short JSON line (no kernels; "
+                         "with --backend gloo this needs no GPU)")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--drones", type=int, default=256, help="drones per GPU per step (configs[1] = 256)")
@@ -685,22 +695,113 @@ def end_to_end(ctx, wp, t, order, calls=60):
             "what": "msnap_solve_batch (host pointers, page-locked): upload, kernel, download, synchronise per call"}
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def resolve_world(args, argv):
+    """The job's rank count from `--gpus` and the launcher environment -- they must agree.
+      * WORLD_SIZE set (torchrun started this rank): that is the world; an explicit --gpus that differs is an error;
+      * no WORLD_SIZE, --gpus N > 1: this process becomes the launcher of N ranks (see launch_ranks) and never
+        touches the GPU itself;
+      * neither: one rank.
+    Returns (world, exit_code): exit_code is not None when this process is done (launcher or error)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        world = int(env_world)
+        if args.gpus is not None and args.gpus != world:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher environment says WORLD_SIZE={world}: "
+                             "refusing to report a job that is not the one asked for (start it as "
+                             f"`python bench.py --gpus {args.gpus}` without a launcher environment, or let "
+                             f"torch.distributed.run start {args.gpus} ranks)\n")
+            return world, 2
+        return world, None
+    n = 1 if args.gpus is None else args.gpus
+    if n < 1:
+        sys.stderr.write(f"bench.py: --gpus {n}: need at least one rank\n")
+        return n, 2
+    if n == 1:
+        return 1, None
+    return n, launch_ranks(args, argv, n)
+
+
+def launch_ranks(args, argv, n):
+    """Start `python -m torch.distributed.run --nproc-per-node n ... bench.py <argv>` and wait for it.  Nothing in
+    this process has called into HIP at this point (argparse only; torch.cuda.device_count() does not initialise the
+    runtime on this image), so no process that holds the GPU is ever replaced or forked: the children are fresh
+    interpreters, one per GPU.  Their stdout/stderr are this process's: rank 0's JSON line passes straight through."""
+    import subprocess
+    if args.backend == "nccl":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} over RCCL needs {n} visible GPUs, this node shows {have}: not "
+                             "starting (a rehearsal on fewer GPUs is `--backend gloo`, whose timings mean nothing)\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_core_count() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, world, rank, local_rank):
+    """--launch-check: the process group of this job and one all-reduce over it, nothing else."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
+    if args.backend == "nccl":
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
+        dist.init_process_group(backend="nccl", device_id=device)
+        one = torch.ones(1, dtype=torch.int64, device=device)
+    else:
+        dist.init_process_group(backend="gloo")
+        one = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(one)
+    counted = int(one.item())
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(),
+                          "backend": dist.get_backend(), "ranks_counted_by_all_reduce": counted}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if counted == world else 3
+
+
 def main():
     args = parse()
+    world, done = resolve_world(args, sys.argv[1:])
+    if done is not None:
+        sys.exit(done)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        sys.exit(launch_check(args, world, rank, local_rank))
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    use_pg = world > 1 or (args.force_pg and "RANK" in os.environ)
+    use_pg = world > 1 or args.force_pg
     if use_pg:
+        if world == 1:      # --force-pg without a launcher: a one-rank group on this process
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)   # RCCL
         else:
@@ -888,6 +989,10 @@ def main():
             "value": total / wall_max,
             "unit": "trajectories/s",
             "n_gpus": world,
+            # what the process group itself says (None: one rank without a process group) -- n_gpus is the same number
+            # by construction (resolve_world), this is the evidence
+            "rccl_ranks": dist.get_world_size() if use_pg else None,
+            "backend": (("nccl (RCCL)" if dist.get_backend() == "nccl" else dist.get_backend()) if use_pg else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": wall_max * 1e3 / args.steps,
