@@ -93,7 +93,7 @@ def built_csrc_sha():
     return csrc_sha()
 
 
-def pmc_traffic(n_drones: int, n_seg: int, order: int, kernel: str = None):
+def pmc_traffic(n_drones: int, n_seg: int, order: int, kernel: str = None, prefix: str = ""):
     """(HBM bytes per launch, source note) of the solve at this workload from the committed PMC passes
     (profiles/pmc_traffic.json, written by tools/make_profiles.sh on an MI355X: separate FETCH_SIZE / WRITE_SIZE
     passes, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction).  The counters are only quoted when
@@ -105,7 +105,7 @@ def pmc_traffic(n_drones: int, n_seg: int, order: int, kernel: str = None):
             rec = json.load(f)
     except Exception:
         return None, "no profiles/pmc_traffic.json"
-    ent = rec.get(f"{n_drones}x{n_seg}o{order}")
+    ent = rec.get(f"{prefix}{n_drones}x{n_seg}o{order}")      # prefix "grid": the shared-grid GEMM's pass
     if not ent:
         return None, "profiles/pmc_traffic.json holds no pass for this workload"
     sha = built_csrc_sha()
@@ -197,7 +197,7 @@ class GridBatch:
         self.dur = torch.empty((self.n, n_seg), dtype=torch.float64, device=device)
         self.status = torch.empty((self.n,), dtype=torch.int32, device=device)
         self._fn = ctx._lib.msnap_solve_grid_device
-        self._args = (ctx._h, self.n, ctypes.c_void_p(self.wp.data_ptr()), ctypes.c_void_p(self.coef.data_ptr()),
+        self._args = (ctx._h, self.n, n_seg, ctypes.c_void_p(self.wp.data_ptr()), ctypes.c_void_p(self.coef.data_ptr()),
                       ctypes.c_void_p(self.dur.data_ptr()), ctypes.c_void_p(self.status.data_ptr()))
 
     def step(self):
@@ -511,8 +511,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     broad = bool(ctx.get_option("collide_last_cull")) if (world == 1 or whole) else False
     shares, survivors = (ctx.get_option("collide_last_shares"), ctx.get_option("collide_last_survivors")) if broad else (0, 0)
     group_pairs = ctx.get_option("collide_last_group_pairs") if broad else 0
-    # the library's own rule (csrc/msnap_aux.hip::cull_use_groups): 8 x 8 group pairs when they are few against the shares
-    by_groups = broad and group_pairs <= (1 << 18) and group_pairs * 141 < survivors * 1485
+    # which list the pass's evaluator walked -- the library's own report (msnap.h "collide_last_by_groups")
+    by_groups = bool(ctx.get_option("collide_last_by_groups")) if broad else False
     mesh_extra = None
     if cfg == 3:
         # how many point-triangle tests the kernel's exact bounding-box cull leaves to evaluate (one counted launch)
@@ -585,15 +585,17 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                           "cull_ratio": pair_exec / S / PAIR_OPS / (N * (N - 1) / 2)} if broad else None),
                          # the work the kernels evaluate (with the broad phase: the surviving shares) over time and peak
                          "frac": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
-                         "frac_on_all_pairs": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
+                         "speedup_vs_all_pairs_issue_peak": pair_alg / world / (st["pairwise"] * 1e-6) / VALU_F64_OPS,
                          "tflops_on_all_pairs": pair_alg / PAIR_OPS * PAIR_FLOPS / world / (st["pairwise"] * 1e-6) / 1e12,
                          "frac_of_attainable": pair_exec / (st["pairwise"] * 1e-6) / VALU_F64_OPS / PAIR_MIX_ATTAINABLE,
                          "note": "frac = the pair-samples the kernels evaluate (N(N-1)/2 + the doubled triangle of the "
                                  "diagonal blocks; behind the broad phase: 128 x 8 per surviving share or 8 x 8 per surviving group pair) x 7 vector "
                                  "instructions (3 differences, d2 = fma(dz, dz, fma(dy, dy, dx*dx)), the minimum; SURVEY.md "
                                  "8d) / the stage's time -- sort, bounds, selection and merge included -- / the fp64 issue "
-                                 "peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); frac_on_all_pairs credits every unordered "
-                                 "pair once, culled or not (it may exceed 1 behind the broad phase); tflops_on_all_pairs "
+                                 "peak (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); speedup_vs_all_pairs_issue_peak is NOT a roofline "
+                                 "fraction: it is how many times faster the stage ran than an all-pairs pass at the issue "
+                                 "peak would (every unordered pair credited once, culled or not; above 1 behind the broad "
+                                 "phase); tflops_on_all_pairs "
                                  "counts that as 9 flops per pair-sample (peak 78.6 with nothing but FMAs), per GPU; "
                                  "frac_of_attainable divides frac by what the bare instruction mix reaches (0.897: "
                                  "tools/micro/f64_rate_micro.hip)"},
@@ -624,14 +626,15 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
             "tests_evaluated_per_s": evaluated / (st["mesh"] * 1e-6),
             # algorithmic work: a full closest-point evaluation is MESH_TEST_OPS fp64 vector operations
             "frac": evaluated * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
-            "frac_on_all_pairs": tests * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
+            "speedup_vs_all_pairs_issue_peak": tests * MESH_TEST_OPS / (st["mesh"] * 1e-6) / VALU_F64_OPS,
             "issue_utilisation": (valu * 64 / (st["mesh"] * 1e-6) / VALU_F64_OPS) if valu else None,
             "issue_utilisation_source": valu_src,
             "note": "exact cull: a triangle whose bounding box is farther from the wave's stretch of path than the best "
                     f"distance so far is skipped (cull_ratio = evaluated / all pairs).  frac = evaluated tests x {MESH_TEST_OPS} "
                     "fp64 vector operations (one full closest-point evaluation, Ericson 5.1.5: the dot products d1..d6, "
                     "the three edge and the face region, the squared distance; counted in csrc/msnap_aux.hip::pt_tri_d2) "
-                    "/ time / fp64 issue peak; frac_on_all_pairs counts the culled pairs as done (it may exceed 1); "
+                    "/ time / fp64 issue peak; speedup_vs_all_pairs_issue_peak counts the culled pairs as done -- not a "
+                    "roofline fraction, it may exceed 1; "
                     "issue_utilisation = SQ_INSTS_VALU x 64 lanes / time / peak from the committed counter pass, quoted "
                     "only when that pass was taken from this build's kernel sources"}
     return rep
@@ -931,6 +934,7 @@ def main():
         wpb[:4096], wpb[-4096:] = wpe[:4096], wpe[4096:]
         gbig = GridBatch(torch, ctx, wpb, M, order, device)
         _, gb_ms = timed_steps(torch, dist, gbig, ctx, 40, 40, False, 1)
+        gk_big = ctx.last_kernel()
         g_err, g_bad = oracle_parity(gbig.coef, wpb, ts, order, np.r_[0:4096, nbig - 4096:nbig])
         assert g_err <= 1e-6 and not g_bad, f"shared-grid saturated leg parity {g_err:.3e}"
         per_s, per_b = g_ms / args.steps * 1e-3, gb_ms / 40 * 1e-3
@@ -943,6 +947,9 @@ def main():
                                "roofline_frac": bs / per_s / 1e9 / HBM_PEAK_GBS},
             "saturated": {"drones": nbig, "value": nbig / per_b, "ms_per_launch": per_b * 1e3,
                           "achieved_GBps": bb / per_b / 1e9, "roofline_frac": bb / per_b / 1e9 / HBM_PEAK_GBS,
+                          "kernel": gk_big, "algorithmic_bytes_per_launch": bb,
+                          "traffic": pmc_traffic(nbig, M, order, gk_big, prefix="grid")[0],
+                          "traffic_source": pmc_traffic(nbig, M, order, gk_big, prefix="grid")[1],
                           "max_norm_rel_err_vs_oracle": g_err},
         }
         del gbig, gsmall

@@ -29,6 +29,7 @@ SIGNATURES = {
     "msnap_last_kernel": (ctypes.c_char_p, [_VP]),
     "msnap_create": (_I, [c_void_pp, _I, _I, _I]),
     "msnap_destroy": (None, [_VP]),
+    "msnap_release_graph_buffers": (_I, [_VP, ctypes.POINTER(ctypes.c_size_t)]),
     "msnap_set_stream": (_I, [_VP, _VP]),
     "msnap_use_own_stream": (_I, [_VP]),
     "msnap_set_option": (_I, [_VP, ctypes.c_char_p, ctypes.c_long]),
@@ -43,8 +44,9 @@ SIGNATURES = {
     "msnap_solve_batch_device": (_I, [_VP, _I, _I, _VP, _VP, _I, _VP, _VP, _VP]),
     "msnap_grid_prepare": (_I, [_VP, _I, _VP]),
     "msnap_grid_prepare_device": (_I, [_VP, _I, _VP]),
-    "msnap_solve_grid": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
-    "msnap_solve_grid_device": (_I, [_VP, _I, _VP, _VP, _VP, _VP]),
+    "msnap_grid_segments": (_I, [_VP]),
+    "msnap_solve_grid": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
+    "msnap_solve_grid_device": (_I, [_VP, _I, _I, _VP, _VP, _VP, _VP]),
     "msnap_pack_pol_matrix": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_pack_pol_matrix_device": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
     "msnap_formation_transform": (_I, [_VP, _I, _I, _VP, _VP, _VP]),
@@ -62,6 +64,8 @@ SIGNATURES = {
     "msnap_sample_collide_device": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _VP, _VP]),
     "msnap_formation_collide_t_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_part_bytes": (ctypes.c_size_t, [_I]),
+    "msnap_formation_collide_takes_broad_phase": (_I, [_VP, _I, _I, _I, _I]),
+    "msnap_formation_whole_pass_pays": (_I, [_VP, _I, _I, ctypes.POINTER(_I)]),
     "msnap_formation_collide_part": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
     "msnap_formation_collide_part_device": (_I, [_VP, _I, _I, _VP, _I, _I, _VP]),
     "msnap_formation_collide_finish": (_I, [_VP, _I, _I, _VP, _I, _I, _D, _VP, _VP, _VP]),

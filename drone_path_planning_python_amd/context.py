@@ -207,7 +207,6 @@ class Context:
         with self._glock:
             with self._lock:
                 self._ck(self._lib.msnap_grid_prepare(self._h, t.shape[0] - 1, pt))
-            self._grid_m = t.shape[0]
             self._grid_host = t.copy()
 
     def ensure_grid(self, t):
@@ -229,43 +228,51 @@ class Context:
         with self._glock:     # (under the grid lock like prepare_grid: solve_on_grid must not see a half-updated grid)
             with self._lock:
                 self._ck(self._lib.msnap_grid_prepare_device(self._h, int(n_seg), _ptr(t)))
-            self._grid_m = int(n_seg) + 1
             self._grid_host = None
+
+    def grid_segments(self) -> int:
+        """Segments of the grid this context holds (msnap_grid_segments; 0: none prepared)."""
+        n = int(self._lib.msnap_grid_segments(self._h))
+        if n < 0:
+            _lib.check(self._lib, self._h, n)
+        return n
 
     def grid_waypoints(self) -> int:
         """Waypoints per drone of the grid this context was last prepared for (raises MSNAP_ENOGRID without one)."""
-        m = getattr(self, "_grid_m", None)
-        if m is None:
+        n = self.grid_segments()
+        if n == 0:
             _lib.check(self._lib, self._h, -7)
-        return int(m)
+        return n + 1
+
+    def release_graph_buffers(self) -> int:
+        """Free the blocks kept alive for graphs captured before a buffer grew (msnap_release_graph_buffers): call
+        once every graph that captured calls of this context is destroyed.  Returns the bytes released."""
+        n = ctypes.c_size_t()
+        with self._lock:
+            self._ck(self._lib.msnap_release_graph_buffers(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def solve_grid(self, wp, out=None):
         """wp [N, m, 4] on the prepared grid -> coef, dur, status (as solve_batch)."""
         with self._glock:
             wp, pwp = _host(wp, np.float64)
-            m = getattr(self, "_grid_m", None)
-            if m is None:
-                _lib.check(self._lib, self._h, -7)
+            m = self.grid_waypoints()
             if wp.ndim != 3 or wp.shape[1:] != (m, 4):
                 raise ValueError(f"wp must be [N, {m}, 4] for the prepared grid")
             N, M = wp.shape[0], m - 1
             coef, dur, status = _out_arrays(out, ((N, M, 4, self.ncoef), (N, M), (N,)))
             with self._lock:
-                self._ck(self._lib.msnap_solve_grid(self._h, N, pwp, coef.ctypes.data_as(ctypes.c_void_p),
+                self._ck(self._lib.msnap_solve_grid(self._h, N, M, pwp, coef.ctypes.data_as(ctypes.c_void_p),
                                                    dur.ctypes.data_as(ctypes.c_void_p),
                                                    status.ctypes.data_as(ctypes.c_void_p)))
             return coef, dur, status
 
-    def solve_grid_device(self, n_drones, wp, coef, dur, status, n_seg=None):
-        """Device pointers.  msnap_solve_grid_device takes no segment count -- it writes n_drones x (segments of
-        the prepared grid) blocks -- so pass `n_seg`, the segment count the buffers were sized for: a mismatch
-        with the prepared grid raises here instead of writing past them."""
-        if n_seg is not None and int(n_seg) + 1 != self.grid_waypoints():
-            raise ValueError(f"solve_grid_device: buffers sized for {int(n_seg)} segments, the prepared grid has "
-                             f"{self.grid_waypoints() - 1}")
+    def solve_grid_device(self, n_drones, n_seg, wp, coef, dur, status):
+        """Device pointers.  `n_seg` is the segment count the buffers were sized for: the library refuses
+        (MSNAP_ESEGMENTS) a count that is not the prepared grid's instead of writing past them."""
         with self._lock:
-            self._ck(self._lib.msnap_solve_grid_device(self._h, int(n_drones), _ptr(wp), _ptr(coef), _ptr(dur),
-                                                      _ptr(status)))
+            self._ck(self._lib.msnap_solve_grid_device(self._h, int(n_drones), int(n_seg), _ptr(wp), _ptr(coef),
+                                                      _ptr(dur), _ptr(status)))
 
     # ---- a7 pack ---------------------------------------------------------------
     def pack_pol_matrix(self, coef, dur):
@@ -371,6 +378,20 @@ class Context:
 
     def collide_rows_t_doubles(self, n_rows: int, n_samples: int) -> int:
         return int(self._lib.msnap_collide_rows_t_doubles(int(n_rows), int(n_samples)))
+
+    def collide_takes_broad_phase(self, n_rows: int, row_offset: int, n_cols: int, n_samples: int) -> bool:
+        """Whether formation_collide with these arguments would run behind the exact broad phase (the library's own
+        predicate: size limits and the "collide_*" options)."""
+        return bool(self._lib.msnap_formation_collide_takes_broad_phase(self._h, int(n_rows), int(row_offset),
+                                                                        int(n_cols), int(n_samples)))
+
+    def whole_pass_pays(self, n_drones: int, n_ranks: int) -> bool:
+        """After a whole-swarm pass: does running it on every one of `n_ranks` ranks beat dividing the pairs (the
+        library's cost model on the counts that pass left; synchronises the stream)?"""
+        pays = ctypes.c_int()
+        with self._lock:
+            self._ck(self._lib.msnap_formation_whole_pass_pays(self._h, int(n_drones), int(n_ranks), ctypes.byref(pays)))
+        return bool(pays.value)
 
     def collide_reads_rows_t(self, n_rows: int, row_offset: int, n_cols: int, n_samples: int) -> bool:
         """Whether formation_collide_t_device with these arguments would read a row image (msnap.h): a whole swarm

@@ -18,14 +18,31 @@ int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what) {
   return MSNAP_EHIP;
 }
 
+bool stream_is_capturing(const msnap_ctx *ctx) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return ctx->stream && hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
 int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes) {
-  if (bytes <= b.cap) return MSNAP_OK;
+  const bool capturing = stream_is_capturing(ctx);
+  if (bytes <= b.cap) {
+    // the launch about to be captured records pointers into this block: from now on a graph may replay on it
+    if (capturing) b.in_graph = true;
+    return MSNAP_OK;
+  }
   // growing synchronises the stream and frees the old block: neither is legal while the stream is being
   // captured into a graph, and a capture must not silently record a launch on a buffer that is about to go
-  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  if (ctx->stream && hipStreamIsCapturing(ctx->stream, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone)
-    return MSNAP_ECAPTURE;
-  if (b.p) {
+  if (capturing) return MSNAP_ECAPTURE;
+  if (b.p && b.in_graph) {
+    // a graph captured earlier may replay on the old block at any time: it is retired, not freed (msnap.h,
+    // "Stream capture"); work queued on it eagerly stays valid for the same reason
+    RetiredBuf *r = new (std::nothrow) RetiredBuf{b.p, b.cap, ctx->retired};
+    if (!r) return MSNAP_ENOMEM;
+    ctx->retired = r;
+    b.p = nullptr;
+    b.cap = 0;
+    b.in_graph = false;
+  } else if (b.p) {
     MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     MSNAP_HIP(ctx, hipFree(b.p));
     b.p = nullptr;
@@ -64,6 +81,8 @@ void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
   va_end(ap);
 }
 
+static bool option_is_read_only(const char *name) { return !strncmp(name, "collide_last_", 13); }
+
 static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "solve_grid_waves")) return &ctx->solve_grid_waves;
   if (!strcmp(name, "gemm_grid_waves")) return &ctx->gemm_grid_waves;
@@ -98,7 +117,7 @@ const char *msnap_strerror(int code) {
     case MSNAP_EINVAL: return "invalid argument";
     case MSNAP_EHIP: return "HIP runtime error (see msnap_last_hip_error)";
     case MSNAP_EORDER: return "unsupported polynomial order (7 or 9)";
-    case MSNAP_ESEGMENTS: return "segment count out of range for this context";
+    case MSNAP_ESEGMENTS: return "segment count out of range for this context, or not the prepared grid's";
     case MSNAP_ENOMEM: return "out of memory";
     case MSNAP_ENODEVICE: return "no usable gfx950 device";
     case MSNAP_ENOGRID: return "no time grid prepared on this context (msnap_grid_prepare)";
@@ -152,6 +171,7 @@ void msnap_destroy(msnap_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  (void)msnap_release_graph_buffers(ctx, nullptr);
   if (ctx->scratch.p) (void)hipFree(ctx->scratch.p);
   if (ctx->mesh_tests) (void)hipFree(ctx->mesh_tests);
   for (msnap::DevBuf *b : {&ctx->grid_t, &ctx->grid_wp, &ctx->grid_op, &ctx->grid_dur, &ctx->grid_status, &ctx->grid_frag})
@@ -170,6 +190,22 @@ void msnap_destroy(msnap_ctx *ctx) {
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
+}
+
+int msnap_release_graph_buffers(msnap_ctx *ctx, size_t *bytes) {
+  if (!ctx) return MSNAP_EINVAL;
+  size_t freed = 0;
+  int rc = MSNAP_OK;
+  (void)hipSetDevice(ctx->device);
+  while (ctx->retired) {
+    RetiredBuf *r = ctx->retired;
+    ctx->retired = r->next;
+    if (hipFree(r->p) != hipSuccess) rc = MSNAP_EHIP;      // (hipFree waits for the device's outstanding work)
+    freed += r->cap;
+    delete r;
+  }
+  if (bytes) *bytes = freed;
+  return rc;
 }
 
 int msnap_set_stream(msnap_ctx *ctx, void *hip_stream) {
@@ -221,6 +257,7 @@ int msnap_set_option(msnap_ctx *ctx, const char *name, long value) {
     }
     return MSNAP_OK;
   }
+  if (option_is_read_only(name)) return MSNAP_EINVAL;      // "collide_last_*": what the last pass did
   int *slot = option_slot(ctx, name);
   if (!slot) return MSNAP_EINVAL;
   *slot = (int)value;
@@ -236,33 +273,31 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
   if (!strcmp(name, "mesh_count_tests")) {   // the count since it was last set (synchronises the stream)
     unsigned long long n = 0;
     if (ctx->mesh_tests) {
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+      if (stream_is_capturing(ctx)) return MSNAP_ECAPTURE;
+      if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
           hipMemcpy(&n, ctx->mesh_tests, 8, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     }
     *value = (long)n;
     return MSNAP_OK;
   }
-  if (!strcmp(name, "collide_last_group_pairs")) {   // surviving group pairs of the last broad-phase pass (synchronises)
-    int32_t n = 0;
-    if (ctx->collide_last_cull && ctx->collide_meta) {
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-          hipMemcpy(&n, ctx->collide_meta + MSNAP_COLLIDE_META_GROUPS, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+  if (!strcmp(name, "collide_last_group_pairs") || !strcmp(name, "collide_last_survivors") ||
+      !strcmp(name, "collide_last_by_groups") || !strcmp(name, "collide_last_pairs_evaluated")) {
+    // counts the last broad-phase pass left on the device (synchronises the stream; not during a capture)
+    int32_t shares = ctx->collide_last_shares, groups = 0;
+    const bool culled = ctx->collide_last_cull && ctx->collide_meta;
+    if (culled) {
+      if (stream_is_capturing(ctx)) return MSNAP_ECAPTURE;
+      if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+          hipMemcpy(&shares, ctx->collide_meta + MSNAP_COLLIDE_META_SHARES, sizeof shares, hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(&groups, ctx->collide_meta + MSNAP_COLLIDE_META_GROUPS, sizeof groups, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     }
-    *value = n;
-    return MSNAP_OK;
-  }
-  if (!strcmp(name, "collide_last_survivors")) {   // of the last broad-phase pass (synchronises the stream)
-    int32_t n = 0;
-    if (ctx->collide_last_cull && ctx->collide_meta) {
-      if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-          hipMemcpy(&n, ctx->collide_meta + MSNAP_COLLIDE_META_SHARES, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
-        return MSNAP_EHIP;
-    } else {
-      n = ctx->collide_last_shares;
-    }
-    *value = n;
+    const bool by_groups = culled && collide_counts_by_groups(ctx, shares, groups);
+    if (!strcmp(name, "collide_last_group_pairs")) *value = groups;
+    else if (!strcmp(name, "collide_last_survivors")) *value = shares;
+    else if (!strcmp(name, "collide_last_by_groups")) *value = by_groups ? 1 : 0;
+    else *value = !culled ? -1 : by_groups ? (long)groups * 64 : (long)shares * 1024;
     return MSNAP_OK;
   }
   const int *slot = option_slot(const_cast<msnap_ctx *>(ctx), name);
@@ -490,20 +525,27 @@ int msnap_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t) {
   return MSNAP_OK;
 }
 
-int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+int msnap_grid_segments(const msnap_ctx *ctx) {
+  if (!ctx) return MSNAP_EINVAL;
+  return ctx->grid_ready ? ctx->grid_seg : 0;
+}
+
+int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double *coef, double *dur,
                             int32_t *status) {
   if (!ctx || n_drones < 0) return MSNAP_EINVAL;
   if (!ctx->grid_ready) return MSNAP_ENOGRID;
+  if (n_seg != ctx->grid_seg) return MSNAP_ESEGMENTS;      // the caller's buffers are sized for another grid
   if (n_drones == 0) return MSNAP_OK;
   if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
   return launch_solve_grid(ctx, n_drones, wp, coef, dur, status);
 }
 
-int msnap_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+int msnap_solve_grid(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double *coef, double *dur,
                      int32_t *status) {
   if (!ctx || n_drones < 0) return MSNAP_EINVAL;
   if (!ctx->grid_ready) return MSNAP_ENOGRID;
+  if (n_seg != ctx->grid_seg) return MSNAP_ESEGMENTS;
   if (n_drones == 0) return MSNAP_OK;
   if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
@@ -604,6 +646,26 @@ size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples) {
 int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
   if (!ctx || n_rows <= 0 || n_cols <= 0 || n_samples < 6) return 0;      // (paths shorter than one sample chunk: plain loops)
   return formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples) ? 0 : 1;
+}
+
+int msnap_formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
+  if (!ctx || n_rows <= 0 || n_cols <= 0 || n_samples < 1 || row_offset < 0) return 0;
+  return formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples) ? 1 : 0;
+}
+
+int msnap_formation_whole_pass_pays(msnap_ctx *ctx, int n_drones, int n_ranks, int *pays) {
+  if (!ctx || !pays || n_drones < 0 || n_ranks < 1) return MSNAP_EINVAL;
+  *pays = 0;
+  long evaluated = -1;
+  int rc = msnap_get_option(ctx, "collide_last_pairs_evaluated", &evaluated);
+  if (rc) return rc;
+  if (evaluated < 0 || n_drones < 2) return MSNAP_OK;      // the last pass evaluated all pairs: the parts divide them
+  // whole pass on every rank: the sort / bound / select launches + the surviving pairs at about 2/3 of the all-pairs
+  // kernel's pace; parts: 1 / n_ranks of all pairs + transposition, merge, fold and the second collective -- the fixed
+  // costs of the two sides are about equal (measured at 4096 drones), which leaves the arithmetic
+  const double all_pairs = 0.5 * (double)n_drones * (double)(n_drones - 1);
+  *pays = ((double)evaluated / all_pairs) * 1.5 * (double)n_ranks < 1.0 ? 1 : 0;
+  return MSNAP_OK;
 }
 
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,

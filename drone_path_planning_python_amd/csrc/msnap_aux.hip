@@ -1832,6 +1832,13 @@ collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, co
   }
 }
 
+bool collide_counts_by_groups(const msnap_ctx *ctx, int shares_surviving, int group_pairs_surviving) {
+  CullGroups cg{};
+  cg.cap = ctx->collide_last_gcap;
+  cg.mode = ctx->collide_last_mode;
+  return cull_use_groups(shares_surviving, group_pairs_surviving, cg);
+}
+
 // whether a pass with these arguments runs behind the exact broad phase (which builds its own, spatially sorted, row
 // image: a caller-provided one is then not read -- msnap_formation_collide_reads_rows_t)
 bool formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
@@ -1936,7 +1943,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   // 2048 x 91 dense 91 -> 121 us, sparse 92 -> 84; 4096 x 91 dense 243 -> 282, sparse 243 -> 122, the formation
   // fixture 243 -> 105)
   const bool cull = g.sym && formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples);
-  ctx->collide_last_cull = cull ? 1 : 0;
+  // (what the last pass did: the broad-phase fields are set together, once its buffer exists)
+  ctx->collide_last_cull = 0;
+  ctx->collide_meta = nullptr;
   ctx->collide_last_shares = (int)(waves < 0x7fffffff ? waves : 0x7fffffff);
   const int E = n_samples * 3;
   if (cull) {
@@ -1976,6 +1985,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     int32_t *glist = meta + kMetaWords, *cand_j = glist + gcap, *pmin = cand_j + (size_t)gcap * 16;
     CullGroups cg{glist, dmin, pmin, cand_d2, cand_j, gcap, ctx->collide_cull_mode};
     ctx->collide_meta = meta;
+    ctx->collide_last_cull = 1;
+    ctx->collide_last_gcap = gcap;
+    ctx->collide_last_mode = ctx->collide_cull_mode;
     hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
                        ctx->stream, pos_cols, N, n_samples, box, key, meta);
     MSNAP_HIP(ctx, hipGetLastError());
@@ -2127,6 +2139,7 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   const size_t t_entries = (size_t)g.Rp * E;
   if ((part_entries + centries) * 12 > ((size_t)16 << 30)) return MSNAP_ENOMEM;
   ctx->collide_last_cull = 0;      // (the buffer the last broad-phase pass left its counts in is reused)
+  ctx->collide_meta = nullptr;
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;

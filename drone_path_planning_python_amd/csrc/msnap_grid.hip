@@ -412,6 +412,8 @@ static int launch_solve_grid_stream(msnap_ctx *ctx, int n_drones, const double *
 int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
                       int32_t *status) {
   const int M = ctx->grid_seg;
+  if (stream_is_capturing(ctx))      // the captured launch holds pointers into the grid's blocks (ensure(), msnap.h)
+    for (DevBuf *b : {&ctx->grid_t, &ctx->grid_frag, &ctx->grid_dur, &ctx->grid_status}) b->in_graph = true;
   if (!grid_gemm_supported(ctx, M)) {
     // more than 63 segments: the K1 solve on the shared grid
     return launch_solve(ctx, n_drones, M, wp, (const double *)ctx->grid_t.p, 1, coef, dur, status);

@@ -7,7 +7,7 @@
 
 #include "../../include/msnap.h"
 
-#define MSNAP_VERSION_NUM 100  /* 0.1.0 */
+#define MSNAP_VERSION_NUM 200  /* 0.2.0: n_seg on msnap_solve_grid[_device], msnap_grid_segments, graph-buffer retention */
 /* int32 words of the pairwise pass's broad-phase hand-over block that msnap_get_option reads back */
 #define MSNAP_COLLIDE_META_SHARES 128
 #define MSNAP_COLLIDE_META_GROUPS 132
@@ -45,6 +45,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  bool in_graph = false;   // a stream capture has used this block: a graph may hold pointers into it (ensure())
+};
+// a block a graph may still replay on, replaced by a larger one: freed by msnap_release_graph_buffers / msnap_destroy
+struct RetiredBuf {
+  void *p;
+  size_t cap;
+  RetiredBuf *next;
 };
 
 }  // namespace msnap
@@ -91,8 +98,10 @@ struct msnap_ctx {
   int collide_last_cull = 0;    // "collide_last_cull" (read): 1 if the last msnap_formation_collide took the broad-phase path
   int collide_last_shares = 0;  // "collide_last_shares" (read): 8-column x 128-row shares of that pass before the broad phase
   const int32_t *collide_meta = nullptr;   // device: its survivor count at [64] ("collide_last_survivors", read: synchronises)
+  int collide_last_gcap = 0, collide_last_mode = 0;   // of that pass: its group-pair list capacity and "collide_cull_mode"
   int collide_last_sym = 0;     // "collide_last_sym" (read): 1 if the last msnap_formation_collide evaluated its own-range pairs once
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
+  msnap::RetiredBuf *retired = nullptr;   // blocks kept alive for graphs captured before they were outgrown
   char hip_err[256] = {0};
   char last_kernel[96] = {0};   // msnap_last_kernel: the solve kernel instance the last solve entry point launched
 };
@@ -101,6 +110,9 @@ namespace msnap {
 
 int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what);
 int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes);
+bool stream_is_capturing(const msnap_ctx *ctx);
+// what the last broad-phase pass evaluated (device-side choice of collide_eval_kernel, restated on its counts)
+bool collide_counts_by_groups(const msnap_ctx *ctx, int shares_surviving, int group_pairs_surviving);
 
 // records the kernel instance a solve launcher chose (msnap_last_kernel; bench.py labels its rooflines with it)
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

@@ -64,7 +64,7 @@ class DeviceCompute:
             side_ctx.use_own_stream()
             self.side = torch_module.cuda.ExternalStream(side_ctx.stream(), device=self.device)
         self._mesh_pending = None
-        self._whole_ok = {}      # (n_total, n_samples, world) -> the broad-phase pass over the whole swarm pays (pairwise_mode)
+        self._whole_ok = {}      # (n_total, n_samples, world) -> {"ok": the whole-swarm pass pays, "since": passes since decided}
 
     def solve(self, wp, t):
         torch = self.torch
@@ -83,15 +83,14 @@ class DeviceCompute:
         torch = self.torch
         n, m, _ = wp.shape
         M = m - 1
-        # msnap_solve_grid_device takes no segment count: it writes n x (segments of the PREPARED grid) blocks.
-        # A batch with another waypoint count would be read and written past its buffers.
+        # (the library refuses a segment count that is not the prepared grid's; the tensor's shape is checked here)
         if wp.dim() != 3 or wp.shape[2] != 4 or m != self.ctx.grid_waypoints():
             raise ValueError(f"solve_grid: wp must be [n, {self.ctx.grid_waypoints()}, 4] for the prepared grid, got {tuple(wp.shape)}")
         coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
         dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
         status = torch.empty((n,), dtype=torch.int32, device=self.device)
         if n:
-            self.ctx.solve_grid_device(n, wp, coef, dur, status, n_seg=M)
+            self.ctx.solve_grid_device(n, M, wp, coef, dur, status)
         return coef, dur, status
 
     def sample(self, coef, dur, dt, n_samples):
@@ -137,41 +136,53 @@ class DeviceCompute:
     # arithmetic is divided by the number of ranks.  "whole": every rank runs the pass over the WHOLE gathered swarm
     # behind the exact broad phase and keeps its rows -- no second collective, and on swarms where the broad phase culls
     # (4096-drone formation fixture: 3 % of the pairs are evaluated, 68 us) that is less than a rank's part of all pairs
-    # plus its collective.  The choice is made from the survivor counts of the first whole pass (one stream
-    # synchronisation, once per swarm shape): identical on every rank, since every rank ran it on the same positions.
+    # plus its collective.  Both inputs of the choice are the library's: whether a whole pass of this shape would run
+    # behind the broad phase (msnap_formation_collide_takes_broad_phase) and whether, by the counts a whole pass left,
+    # it pays against the parts (msnap_formation_whole_pass_pays) -- no threshold or cost constant lives here.  Every
+    # rank ran the pass on the same positions and gets the same counts; they still agree through one MIN all-reduce.
+    REPROBE_EVERY = 256      # passes after which a shape that went to the parts tries one whole pass again
+
     def pairwise_mode(self, n_total, n_samples, world):
         key = (int(n_total), int(n_samples), int(world))
-        if world == 1 or self._whole_ok.get(key) is False:
+        if world == 1:
             return "parts"
-        # would the library run the whole-swarm pass behind the broad phase at all? (size limits, "collide_no_cull")
-        return "whole" if not self.ctx.collide_reads_rows_t(n_total, 0, n_total, n_samples) and n_samples >= 6 else "parts"
+        st = self._whole_ok.get(key)
+        if st is not None and not st["ok"] and st["since"] < self.REPROBE_EVERY:
+            return "parts"
+        return "whole" if self.ctx.collide_takes_broad_phase(n_total, 0, n_total, n_samples) else "parts"
+
+    def note_parts_pass(self, n_total, n_samples, world):
+        """After a pass in parts: counts towards the next re-probe of the whole-swarm mode (a swarm that was dense
+        when the decision was taken may have spread out since)."""
+        st = self._whole_ok.get((int(n_total), int(n_samples), int(world)))
+        if st is not None and not st["ok"]:
+            st["since"] += 1
 
     def note_whole_pass(self, n_total, n_samples, world, dist=None):
-        """After a whole-swarm pass: decide once whether it pays against the parts (reads the pass's survivor counts).
-        With `dist` the ranks take the decision together (a MIN all-reduce of one flag, once per swarm shape): they all
-        ran the pass on the same positions and get the same counts, but a split decision would leave them in
-        different collectives."""
+        """After a whole-swarm pass: decide whether it pays against the parts -- on the first pass of a swarm shape,
+        on a re-probe, and every REPROBE_EVERY whole passes (a sparse swarm may have contracted).  Reads the pass's
+        survivor counts (one stream synchronisation).  With `dist` the ranks take the decision together (a MIN
+        all-reduce of one flag): a split decision would leave them in different collectives, so the all-reduce is
+        entered whatever happened locally -- a rank whose query failed contributes 0 (parts) and re-raises after it."""
         key = (int(n_total), int(n_samples), int(world))
-        if key in self._whole_ok:
-            return
-        self._whole_ok[key] = self._whole_pays(n_total, world)
+        st = self._whole_ok.get(key)
+        if st is not None and st["ok"]:
+            st["since"] += 1
+            if st["since"] < self.REPROBE_EVERY:
+                return
+        err = None
+        try:
+            ok = bool(self.ctx.whole_pass_pays(n_total, world))
+        except Exception as e:      # (e.g. MSNAP_ECAPTURE: the query synchronises, the stream is being captured)
+            ok, err = False, e
         if dist is not None and world > 1:
-            flag = self.torch.tensor([1 if self._whole_ok[key] else 0], dtype=self.torch.int32,
+            flag = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32,
                                      device=self.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            self._whole_ok[key] = bool(int(flag.item()))
-
-    def _whole_pays(self, n_total, world):
-        if not self.ctx.get_option("collide_last_cull"):
-            return False
-        shares, surv = self.ctx.get_option("collide_last_shares"), self.ctx.get_option("collide_last_survivors")
-        groups = self.ctx.get_option("collide_last_group_pairs")
-        by_groups = groups <= (1 << 18) and groups * 141 < surv * 1485          # csrc/msnap_aux.hip::cull_use_groups
-        evaluated = groups * 64.0 if by_groups else surv * 1024.0
-        ratio = evaluated / max(1.0, n_total * (n_total - 1) / 2.0)
-        # whole: the small launches (~45 us at 4096 drones) + ratio x 1.5 of the all-pairs time; parts: 1 / world of it
-        # + transposition, merge, fold and the second collective (~45 us)
-        return ratio * 1.5 * world < 1.0
+            ok = bool(int(flag.item()))
+        self._whole_ok[key] = {"ok": ok, "since": 0}
+        if err is not None:
+            raise err
 
     def collide_part(self, pos_all, part, n_parts):
         """This rank's part of the pass over the whole swarm: uint8 [formation_part_bytes(N)] (squared minima
@@ -258,15 +269,16 @@ class FormationResult:
     mesh_hit: object = None
 
 
-def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, torch):
-    """All-gather the ranks' [n_r, S, 3] position blocks into [N, S, 3].
+def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, torch, force: bool = False):
+    """All-gather the ranks' [n_r, S, 3] position blocks into [N, S, 3].  `force`: issue the collective on a
+    one-rank group too (a one-GPU box then runs the same RCCL call a multi-GPU job makes).
 
     Shards may differ by one drone, so every rank pads to the largest shard, one
     `all_gather_into_tensor` moves the padded blocks (a single collective: RCCL
     picks a direct all-gather on the xGMI full mesh; the message is latency bound,
     SURVEY.md 8e) and the padding is dropped afterwards."""
     sizes = shard_sizes(n_total, world)
-    if world == 1:
+    if world == 1 and not force:
         return pos_local
     S = pos_local.shape[1]
     nmax = max(sizes)
@@ -282,10 +294,10 @@ def all_gather_positions(pos_local, n_total: int, world: int, rank: int, dist, t
     return torch.cat(parts, dim=0)
 
 
-def all_gather_parts(part_local, world: int, dist, torch):
+def all_gather_parts(part_local, world: int, dist, torch, force: bool = False):
     """All-gather the ranks' part blocks (uint8 [B] each) into [world, B]: the second, small collective of the
-    formation pass (12 bytes per drone and rank)."""
-    if world == 1:
+    formation pass (12 bytes per drone and rank).  `force` as in all_gather_positions."""
+    if world == 1 and not force:
         return part_local.reshape(1, -1)
     gathered = torch.empty((world * part_local.shape[0],), dtype=part_local.dtype, device=part_local.device)
     dist.all_gather_into_tensor(gathered, part_local.contiguous())
@@ -294,7 +306,7 @@ def all_gather_parts(part_local, world: int, dist, torch):
 
 def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, rank: int, dt: float,
                    n_samples: int, radius: float, dist=None, torch=None, status_local=None,
-                   mesh_tris=None) -> FormationResult:
+                   mesh_tris=None, force_collectives: bool = False, force_mode: str = None) -> FormationResult:
     """Sample the local shard, exchange, evaluate this rank's part of the swarm's pairs, exchange the
     partial minima and fold them for the own rows (one rank: one symmetric launch, no exchange); with
     `mesh_tris` ([T, 3, 3]) also sweep the local shard against the mesh, started right behind the sampler
@@ -302,13 +314,25 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
 
     `status_local` (the solve's per-drone status of this shard): a failed solve leaves NaN
     coefficients, and NaN samples never win a minimum (include/msnap.h) -- such a drone would
-    read as collision-free and be invisible to the others, so it is refused here."""
+    read as collision-free and be invisible to the others, so it is refused here.
+
+    `force_collectives`: take the several-rank route -- both collectives, parts and fold, or the whole-swarm mode --
+    on a one-rank group as well (what a one-GPU box can execute of the multi-GPU path); `force_mode` ("parts" /
+    "whole") pins the pairwise mode instead of asking `compute.pairwise_mode`."""
     lo, hi = shard_bounds(n_total, world, rank)
     if status_local is not None and int(abs(status_local).sum()) != 0:
         raise ValueError("formation_pass: the solve reported failed drones (status != 0) in rows "
                          f"[{lo}, {hi}); their samples are NaN and cannot be collision-checked")
+    multi = world > 1 or force_collectives
+    if multi:
+        mode = force_mode or (compute.pairwise_mode(n_total, n_samples, world) if hasattr(compute, "pairwise_mode") else "parts")
+        # checked before the first collective: a compute object without the calls this mode needs must not leave
+        # the other ranks waiting in an all-gather this rank never enters
+        if mode == "parts" and not (hasattr(compute, "collide_part") and hasattr(compute, "collide_finish")):
+            raise TypeError("formation_pass on several ranks needs compute.collide_part / collide_finish "
+                            "(every pair on exactly one rank); this compute object only has collide()")
     rows_t = None
-    if world == 1 and hasattr(compute, "sample_rows_t"):
+    if not multi and hasattr(compute, "sample_rows_t"):
         pos_local, rows_t = compute.sample_rows_t(coef_local, dur_local, dt, n_samples, n_cols=n_total)
     else:
         pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
@@ -316,16 +340,18 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
     if overlapped:
         compute.mesh_begin(pos_local, mesh_tris, radius)
     try:
-        if world > 1:
-            pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch)
-            mode = compute.pairwise_mode(n_total, n_samples, world) if hasattr(compute, "pairwise_mode") else "parts"
+        if multi:
+            pos_all = all_gather_positions(pos_local, n_total, world, rank, dist, torch, force=force_collectives)
             if mode == "whole":
                 md, partner, hit = (x[lo:hi] for x in compute.collide(pos_all, 0, pos_all, radius))
-                compute.note_whole_pass(n_total, n_samples, world, dist if hasattr(dist, "get_backend") else None)
+                if hasattr(compute, "note_whole_pass"):
+                    compute.note_whole_pass(n_total, n_samples, world, dist if hasattr(dist, "get_backend") else None)
             else:
                 part = compute.collide_part(pos_all, rank, world)
-                parts = all_gather_parts(part, world, dist, torch)
+                parts = all_gather_parts(part, world, dist, torch, force=force_collectives)
                 md, partner, hit = compute.collide_finish(parts, n_total, lo, hi - lo, radius)
+                if hasattr(compute, "note_parts_pass"):
+                    compute.note_parts_pass(n_total, n_samples, world)
         else:
             pos_all = pos_local
             if rows_t is not None:
@@ -337,9 +363,15 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
             mmd, mhit = compute.mesh_end()
         elif mesh_tris is not None:
             mmd, mhit = compute.mesh(pos_local, mesh_tris, radius)
-    finally:
+    except BaseException as first:
+        # join the side stream before the sweep's buffers can be recycled -- and keep the FIRST exception: after a
+        # HIP error the join will most likely fail too and would otherwise replace the cause
         if overlapped and hasattr(compute, "mesh_abort"):
-            compute.mesh_abort()      # (a no-op unless something above raised between begin and end)
+            try:
+                compute.mesh_abort()
+            except Exception as second:
+                first.__context__ = second
+        raise
     return FormationResult(lo, hi, md, partner, hit, pos_all, mmd, mhit)
 
 

@@ -49,9 +49,21 @@ enum msnap_error {
   MSNAP_ENODEVICE = -6,   /* no gfx950 device / device_id out of range        */
   MSNAP_ENOGRID = -7,     /* msnap_solve_grid without a prepared grid          */
   MSNAP_ECAPTURE = -8     /* a scratch buffer of the context would have to grow while its stream is being
-                             captured into a graph (growing synchronises and frees): run the same call once
-                             outside the capture first -- the buffers then have their size */
+                             captured into a graph (growing synchronises and frees), or a query that has to
+                             synchronise the stream was made during a capture: run the same call once outside the
+                             capture first -- the buffers then have their size */
 };
+
+/* Stream capture (hipGraph) and the context's scratch buffers.  A call captured into a graph records raw pointers
+ * into the context's internal buffers.  The library therefore remembers every buffer a capture has used: when a
+ * LATER call (eager, or another capture) needs such a buffer larger, the old block is not freed -- it is retired and
+ * stays valid until msnap_destroy or msnap_release_graph_buffers -- so a graph instantiated earlier keeps replaying
+ * on memory that is still its own and still gives the result of the pass it captured.  A replay does not see options
+ * set after the capture; a graph that captured msnap_solve_grid_device is tied to the grid prepared at that time --
+ * preparing another grid on the context invalidates it (its memory stays valid, its results do not).  msnap_release_graph_buffers frees the retired
+ * blocks: call it once every graph that captured calls of this context has been destroyed; it returns the number of
+ * bytes released through *bytes (may be NULL). */
+int msnap_release_graph_buffers(msnap_ctx *ctx, size_t *bytes);
 
 enum msnap_status {       /* per-drone, written to status[]                   */
   MSNAP_ST_OK = 0,
@@ -110,7 +122,8 @@ int msnap_host_free(void *ptr);
  *                          companions: "collide_last_cull" (1 if the last pass took the broad phase),
  *                          "collide_last_shares" (its 128 x 8 shares before the test), "collide_last_survivors"
  *                          (the shares that pass it) and "collide_last_group_pairs" (the 8 x 8 group pairs that
- *                          pass it; both synchronise the stream)
+ *                          pass it; both synchronise the stream).  msnap_set_option refuses the read-only names
+ *                          ("collide_last_*") with MSNAP_EINVAL
  *   "collide_cull_mode"    what the broad phase evaluates: 0 (default) chosen per pass on the device -- the surviving
  *                          8 x 8 group pairs when they are few against the surviving 128 x 8 shares --, 1 always
  *                          the shares, 2 always the group pairs (while their list holds them: 262144)
@@ -162,12 +175,17 @@ int msnap_solve_batch_device(msnap_ctx *ctx, int n_drones, int n_seg, const doub
  *   msnap_solve_grid    applies it to n_drones waypoint sets: same outputs as
  *                       msnap_solve_batch(.., t, shared_times = 1, ..).
  * The operator stays valid until the next msnap_grid_prepare on this context.
+ * n_seg of msnap_solve_grid[_device] is the segment count the CALLER sized wp / coef / dur for (as in
+ * msnap_solve_batch): it must equal the prepared grid's, else MSNAP_ESEGMENTS and nothing is written -- the reference
+ * call sizes its output from its input (calculatingTrajectories.py:45-49), a C caller's buffers cannot be inspected.
+ * msnap_grid_segments: segments of the grid this context holds (0: none prepared, negative: error).
  */
 int msnap_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t /* host [n_seg+1] */);
 int msnap_grid_prepare_device(msnap_ctx *ctx, int n_seg, const double *t /* device */);
-int msnap_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
+int msnap_grid_segments(const msnap_ctx *ctx);
+int msnap_solve_grid(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double *coef, double *dur,
                      int32_t *status);
-int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, const double *wp, double *coef,
+int msnap_solve_grid_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double *coef,
                             double *dur, int32_t *status);
 
 /* ---- a7: the float32 [T | x | y | z | yaw] matrix of path_to_pol -----------------
@@ -285,6 +303,22 @@ int msnap_formation_collide_t_device(msnap_ctx *ctx, int n_rows, int row_offset,
  *   parts [n_parts] blocks of msnap_formation_part_bytes(n_drones) bytes, part p at offset p * that
  */
 size_t msnap_formation_part_bytes(int n_drones);
+/* Who evaluates which pairs on several ranks is a choice between the parts above and "every rank runs the pass over
+ * the whole gathered swarm behind the exact broad phase and keeps its rows" (one collective instead of two; pays when
+ * the broad phase leaves few pairs).  Both inputs of that choice are the library's own and are exported here, so that
+ * a host does not re-type launch thresholds or cost-model constants:
+ *   msnap_formation_collide_takes_broad_phase  1 if msnap_formation_collide[_device] with these arguments would run
+ *       behind the broad phase (size limits, "collide_no_cull", "collide_no_sym", "collide_cull_min_drones"), else 0;
+ *   msnap_formation_whole_pass_pays  after a whole-swarm pass of n_drones on this context: *pays = 1 if, by the
+ *       counts that pass left (pairs it evaluated: 8 x 8 per surviving group pair or 128 x 8 per surviving share,
+ *       whichever list its evaluator walked) and the evaluator's cost model, the whole pass on every one of n_ranks
+ *       ranks is quicker than a rank's 1 / n_ranks of all pairs plus the second collective; 0 if not, or if the last
+ *       pass did not take the broad phase.  Synchronises the stream (MSNAP_ECAPTURE during a capture).
+ * Read-only options of the same pass: "collide_last_by_groups" (1: its evaluator walked the group pairs) and
+ * "collide_last_pairs_evaluated" (drone pairs it evaluated); both synchronise. */
+int msnap_formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
+                                              int n_samples);
+int msnap_formation_whole_pass_pays(msnap_ctx *ctx, int n_drones, int n_ranks, int *pays);
 int msnap_formation_collide_part(msnap_ctx *ctx, int n_drones, int n_samples, const double *pos_all,
                                  int part, int n_parts, void *part_out);
 int msnap_formation_collide_part_device(msnap_ctx *ctx, int n_drones, int n_samples,

@@ -60,8 +60,10 @@ int main(void) {
   EXPECT(msnap_solve_batch_device(NULL, 1, 3, d, d, 0, d, d, i) == MSNAP_EINVAL);
   EXPECT(msnap_grid_prepare(NULL, 3, d) == MSNAP_EINVAL);
   EXPECT(msnap_grid_prepare_device(NULL, 3, d) == MSNAP_EINVAL);
-  EXPECT(msnap_solve_grid(NULL, 1, d, d, d, i) == MSNAP_EINVAL);
-  EXPECT(msnap_solve_grid_device(NULL, 1, d, d, d, i) == MSNAP_EINVAL);
+  EXPECT(msnap_grid_segments(NULL) == MSNAP_EINVAL);
+  EXPECT(msnap_solve_grid(NULL, 1, 3, d, d, d, i) == MSNAP_EINVAL);
+  EXPECT(msnap_solve_grid_device(NULL, 1, 3, d, d, d, i) == MSNAP_EINVAL);
+  EXPECT(msnap_release_graph_buffers(NULL, NULL) == MSNAP_EINVAL);
   EXPECT(msnap_pack_pol_matrix(NULL, 1, 1, d, d, f) == MSNAP_EINVAL);
   EXPECT(msnap_pack_pol_matrix_device(NULL, 1, 1, d, d, f) == MSNAP_EINVAL);
   EXPECT(msnap_formation_transform(NULL, 1, 1, d, d, d) == MSNAP_EINVAL);
@@ -80,6 +82,11 @@ int main(void) {
   EXPECT(msnap_formation_collide_t_device(NULL, 1, 0, 1, 2, d, d, d, 0.1, d, i, i) == MSNAP_EINVAL);
   EXPECT(msnap_formation_part_bytes(0) == 0 && msnap_formation_part_bytes(-3) == 0);
   EXPECT(msnap_formation_part_bytes(1) == 16 && msnap_formation_part_bytes(2) == 24 && msnap_formation_part_bytes(4096) == 49152);
+  EXPECT(msnap_formation_collide_takes_broad_phase(NULL, 4096, 0, 4096, 91) == 0);
+  {
+    int pays = 7;
+    EXPECT(msnap_formation_whole_pass_pays(NULL, 4096, 8, &pays) == MSNAP_EINVAL);
+  }
   EXPECT(msnap_formation_collide_part(NULL, 2, 2, d, 0, 1, bytes) == MSNAP_EINVAL);
   EXPECT(msnap_formation_collide_part_device(NULL, 2, 2, d, 0, 1, bytes) == MSNAP_EINVAL);
   EXPECT(msnap_formation_collide_finish(NULL, 2, 1, bytes, 0, 2, 0.1, d, i, i) == MSNAP_EINVAL);

@@ -38,6 +38,23 @@ int main(void) {
   float row[3][33];
   rc = msnap_pack_pol_matrix(ctx, 1, 3, &coef[0][0][0], dur, &row[0][0]);
   if (rc != MSNAP_OK) return 4;
+  /* the same solve on a prepared shared grid: the segment count is the caller's statement of what its buffers
+   * hold -- another count than the grid's is refused (MSNAP_ESEGMENTS) and nothing is written */
+  double gcoef[3][4][8], gdur[3];
+  int32_t gstatus[1] = {77};
+  if (msnap_grid_segments(ctx) != 0) return 7;
+  if (msnap_solve_grid(ctx, 1, 3, &wp[0][0], &gcoef[0][0][0], gdur, gstatus) != MSNAP_ENOGRID) return 8;
+  if (msnap_grid_prepare(ctx, 3, t) != MSNAP_OK || msnap_grid_segments(ctx) != 3) return 9;
+  gcoef[0][0][0] = -12345.0;
+  if (msnap_solve_grid(ctx, 1, 4, &wp[0][0], &gcoef[0][0][0], gdur, gstatus) != MSNAP_ESEGMENTS) return 10;
+  if (msnap_solve_grid(ctx, 1, 2, &wp[0][0], &gcoef[0][0][0], gdur, gstatus) != MSNAP_ESEGMENTS) return 11;
+  if (gcoef[0][0][0] != -12345.0 || gstatus[0] != 77) return 12;
+  if (msnap_solve_grid(ctx, 1, 3, &wp[0][0], &gcoef[0][0][0], gdur, gstatus) != MSNAP_OK || gstatus[0] != MSNAP_ST_OK) return 13;
+  for (int s = 0; s < 3; ++s)
+    for (int a = 0; a < 4; ++a)
+      for (int k = 0; k < 8; ++k) err = fmax(err, fabs(gcoef[s][a][k] - coef[s][a][k]));
+  size_t released = 1;
+  if (msnap_release_graph_buffers(ctx, &released) != MSNAP_OK || released != 0) return 14;
   msnap_destroy(ctx);
   printf("version %d  dur %.1f %.1f %.1f  max abs err %.3e  row[1][1]=%.7f\n", msnap_version(), dur[0], dur[1], dur[2], err,
          row[1][1]);

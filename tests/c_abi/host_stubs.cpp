@@ -20,6 +20,7 @@ int launch_formation_collide(msnap_ctx *, int, int, int, int, const double *, co
                              int32_t *, const double *) { return unreachable(); }
 int launch_formation_collide_part(msnap_ctx *, int, int, const double *, int, int, double *, int32_t *) { return unreachable(); }
 bool formation_collide_takes_broad_phase(const msnap_ctx *, int, int, int, int) { return false; }
+bool collide_counts_by_groups(const msnap_ctx *, int, int) { return false; }
 int launch_formation_collide_finish(msnap_ctx *, int, int, const void *, size_t, int, int, double, double *, int32_t *,
                                     int32_t *) { return unreachable(); }
 int launch_mesh_sweep(msnap_ctx *, int, int, const double *, int, const double *, double, double *, int32_t *) { return unreachable(); }

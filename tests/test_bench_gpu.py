@@ -23,6 +23,7 @@ def test_bench_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert d["rccl_ranks"] is None and d["backend"] is None      # one rank, no process group
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 1e5                                       # the north-star floor: 100 k trajectories/s
@@ -44,7 +45,7 @@ def test_bench_line_contract():
     assert cfg["4"]["max_norm_rel_err_vs_oracle"] <= 1e-6
     assert set(cfg["3"]["stage_us"]) == {"solve", "sample", "pairwise", "mesh"}
     pw = cfg["2"]["stages"]["pairwise"]
-    assert 0.0 < pw["frac"] < 1.0 and pw["frac_on_all_pairs"] >= pw["frac"]
+    assert 0.0 < pw["frac"] < 1.0 and pw["speedup_vs_all_pairs_issue_peak"] >= pw["frac"] and "frac_on_all_pairs" not in pw
     bp = pw["broad_phase"]
     assert bp is not None and 0 < bp["shares_surviving"] <= bp["shares"] and 0 < bp["group_pairs_surviving"] <= bp["group_pairs"]
     assert 0.0 < bp["cull_ratio"] < 1.0
@@ -57,7 +58,7 @@ def test_bench_line_contract():
         assert isinstance(rec["traffic_source"], str) and len(rec["traffic_source"]) > 10
         assert rec["traffic"] is None or "csrc" in rec["traffic_source"]
     mesh = cfg["3"]["stages"]["mesh"]
-    assert 0.0 < mesh["cull_ratio"] < 1.0 and 0.0 < mesh["frac"] < 1.0 and mesh["frac_on_all_pairs"] > mesh["frac"]
+    assert 0.0 < mesh["cull_ratio"] < 1.0 and 0.0 < mesh["frac"] < 1.0 and mesh["speedup_vs_all_pairs_issue_peak"] > mesh["frac"]
     ss = d["strong_scaling"]
     assert ss["n_gpus"] == 1 and {"solve_order9_65536x10", "solve_order7_65536x10", "formation_4096x10",
                                   "formation_16384x10"} <= set(ss)

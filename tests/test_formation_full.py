@@ -368,6 +368,92 @@ def test_broad_phase_pass_replays_from_a_graph():
 
 
 @pytest.mark.gpu
+def test_a_captured_pass_survives_a_later_larger_pass():
+    """A graph holds raw pointers into the context's scratch block.  A later EAGER pass that needs the block larger
+    must not free it under the graph (msnap.h "Stream capture"): the old block is retired, the graph keeps replaying
+    the pass it captured with the right results, and msnap_release_graph_buffers frees it once the graph is gone."""
+    import torch
+    from drone_path_planning_python_amd import Context
+    rng = np.random.default_rng(5)
+    n, S, nbig = 3072, 13, 6000
+    dev = torch.device("cuda", 0)
+    pos = torch.from_numpy(_broad_phase_swarm("teams", n, S, rng)).to(dev)
+    big = torch.from_numpy(_broad_phase_swarm("sparse", nbig, S, rng)).to(dev)
+    md, partner, hit = (torch.empty((nbig,), dtype=dt, device=dev) for dt in (torch.float64, torch.int32, torch.int32))
+    ref = c_oracle.formation_collide(pos.cpu().numpy(), 0.3)
+    ref_big = c_oracle.formation_collide(big.cpu().numpy(), 0.3)
+    side = torch.cuda.Stream()
+    with Context(order=7, max_segments=16) as ctx:
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            ctx.formation_collide_device(n, 0, n, S, pos, pos, 0.3, md, partner, hit)      # sizes the buffers
+            side.synchronize()
+            assert ctx.release_graph_buffers() == 0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+                # a query that has to synchronise is refused inside the capture instead of invalidating it
+                with pytest.raises(Exception) as ei:
+                    ctx.get_option("collide_last_survivors")
+                assert getattr(ei.value, "code", None) == -8
+                ctx.formation_collide_device(n, 0, n, S, pos, pos, 0.3, md, partner, hit)
+            ctx.set_stream(side.cuda_stream)
+            # the eager pass needs a much larger block: without retention this frees the graph's memory
+            ctx.formation_collide_device(nbig, 0, nbig, S, big, big, 0.3, md, partner, hit)
+            side.synchronize()
+            np.testing.assert_array_equal(md.cpu().numpy(), ref_big[0])
+            np.testing.assert_array_equal(partner.cpu().numpy(), ref_big[1])
+            for _ in range(3):
+                md.fill_(-1.0)
+                partner.fill_(-7)
+                g.replay()
+                side.synchronize()
+                np.testing.assert_array_equal(md[:n].cpu().numpy(), ref[0])
+                np.testing.assert_array_equal(partner[:n].cpu().numpy(), ref[1])
+                np.testing.assert_array_equal(hit[:n].cpu().numpy().astype(bool), ref[2])
+                # and the larger pass still works beside it
+                ctx.formation_collide_device(nbig, 0, nbig, S, big, big, 0.3, md, partner, hit)
+                side.synchronize()
+                np.testing.assert_array_equal(md.cpu().numpy(), ref_big[0])
+            del g
+            side.synchronize()
+            assert ctx.release_graph_buffers() > 0
+            assert ctx.release_graph_buffers() == 0
+        ctx.use_own_stream()
+
+
+@pytest.mark.gpu
+def test_read_only_options_and_last_pass_reports(ctx7):
+    """"collide_last_*" report what the last pass did and cannot be set; "collide_last_by_groups" /
+    "collide_last_pairs_evaluated" and msnap_formation_whole_pass_pays are the library's own statements of its
+    device-side choice (what bench.py and swarm.py read instead of re-typing the cost model)."""
+    from drone_path_planning_python_amd._lib import MsnapError
+    rng = np.random.default_rng(8)
+    n, S = 3072, 12
+    for name in ("collide_last_cull", "collide_last_shares", "collide_last_sym", "collide_last_survivors",
+                 "collide_last_group_pairs", "collide_last_by_groups", "collide_last_pairs_evaluated"):
+        with pytest.raises(MsnapError):
+            ctx7.set_option(name, 1)
+    assert ctx7.collide_takes_broad_phase(n, 0, n, S) and not ctx7.collide_takes_broad_phase(n, 0, n + 1, S)
+    assert not ctx7.collide_takes_broad_phase(1024, 0, 1024, S) and not ctx7.collide_takes_broad_phase(n, 0, n, 3)
+    sparse = _broad_phase_swarm("sparse", n, S, rng)
+    ctx7.formation_collide(sparse, sparse, 0.3)
+    surv, groups = ctx7.get_option("collide_last_survivors"), ctx7.get_option("collide_last_group_pairs")
+    by_groups, pairs = ctx7.get_option("collide_last_by_groups"), ctx7.get_option("collide_last_pairs_evaluated")
+    assert ctx7.get_option("collide_last_cull") == 1 and 0 < surv <= ctx7.get_option("collide_last_shares")
+    assert pairs == (groups * 64 if by_groups else surv * 1024) and pairs < n * (n - 1) // 2 // 8
+    assert ctx7.whole_pass_pays(n, 4) and ctx7.whole_pass_pays(n, 8)
+    dense = _broad_phase_swarm("dense", n, S, rng)
+    ctx7.formation_collide(dense, dense, 0.3)
+    assert ctx7.get_option("collide_last_by_groups") == 0
+    assert ctx7.get_option("collide_last_pairs_evaluated") >= n * (n - 1) // 2
+    assert not ctx7.whole_pass_pays(n, 2)
+    ctx7.formation_collide(dense[:1000], dense[:1000], 0.3)       # not a broad-phase pass: nothing to report
+    assert ctx7.get_option("collide_last_cull") == 0 and ctx7.get_option("collide_last_pairs_evaluated") == -1
+    assert ctx7.get_option("collide_last_group_pairs") == 0 and not ctx7.whole_pass_pays(1000, 4)
+
+
+@pytest.mark.gpu
 def test_multi_rank_pairwise_mode_follows_the_survivor_counts(ctx7):
     """swarm.DeviceCompute.pairwise_mode: several ranks run the whole gathered swarm behind the broad phase where it
     culls, and fall back to the parts (every pair on one rank) where it does not -- decided once per swarm shape from

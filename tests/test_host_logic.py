@@ -242,12 +242,11 @@ def test_fma_square_is_exactly_rounded():
 
 
 def test_device_solve_grid_refuses_batches_that_do_not_match_the_prepared_grid():
-    """msnap_solve_grid_device takes no segment count: it writes n x (segments of the prepared grid) blocks.  The
-    device wrappers must refuse a batch sized for another grid before anything is launched (no GPU needed: the
-    context is a stand-in that counts launches)."""
-    import threading
+    """The library itself refuses a segment count that is not the prepared grid's (MSNAP_ESEGMENTS,
+    tests/c_abi/abi_smoke.c); the torch wrapper additionally checks the tensor shapes before anything is launched (no
+    GPU needed: the context is a stand-in that counts launches)."""
     import torch
-    from drone_path_planning_python_amd import Context, swarm
+    from drone_path_planning_python_amd import swarm
 
     class FakeCtx:
         ncoef = 8
@@ -256,7 +255,7 @@ def test_device_solve_grid_refuses_batches_that_do_not_match_the_prepared_grid()
         def grid_waypoints(self):
             return 11
 
-        def solve_grid_device(self, n, wp, coef, dur, status, n_seg=None):
+        def solve_grid_device(self, n, n_seg, wp, coef, dur, status):
             assert n_seg == 10 and tuple(coef.shape) == (n, 10, 4, 8)
             self.launches += 1
 
@@ -269,8 +268,3 @@ def test_device_solve_grid_refuses_batches_that_do_not_match_the_prepared_grid()
     assert comp.ctx.launches == 0
     comp.solve_grid(torch.zeros((4, 11, 4), dtype=torch.float64))
     assert comp.ctx.launches == 1
-    # and the Context-level wrapper: buffers sized for another segment count than the prepared grid
-    ctx = object.__new__(Context)
-    ctx._grid_m, ctx._lock = 11, threading.Lock()
-    with pytest.raises(ValueError):
-        ctx.solve_grid_device(4, 0, 0, 0, 0, n_seg=20)

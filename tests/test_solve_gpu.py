@@ -218,6 +218,53 @@ def test_order9_against_generalised_oracle(ctx9, m):
     np.testing.assert_array_equal(dur, rdur)
 
 
+def test_long_lived_context_after_many_short_lived_ones(ctx9, gold9):
+    """The sequence of round 3's one abort (gpurun_out/r3w_pytest.log): a long-lived context on its
+    OWN stream has run small instances; fifteen short-lived contexts are created, run every kernel family of their
+    segment count and are destroyed (streams, staging, bounce buffers and events freed each time); then the long-lived
+    context launches, for the first time, the instances of 13..20 segments -- from host pointers, then from device
+    pointers on a borrowed torch stream.  Every result is checked; no kernel of the library uses scratch
+    (tests/test_abi.py), which is what the aborting build differed in."""
+    import torch
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    wp, t = swarm(71, 18, 4)
+    assert (ctx9.solve_batch(wp, t)[2] == 0).all()
+    for name in ORDER9_CASES:
+        wpn, tn = gold9[name + "_wp"], gold9[name + "_t"]
+        with Context(order=9, max_segments=64) as ctx:
+            for opt in (None, "no_twist", "no_twin"):
+                if opt:
+                    ctx.set_option(opt, 1)
+                assert (ctx.solve_batch(wpn, tn)[2] == 0).all()
+            big_wp, big_t = swarm(72, 3000, wpn.shape[1] - 1)
+            assert (ctx.solve_batch(big_wp, big_t)[2] == 0).all()      # the staged (non-bounce) host path too
+    for m in (16, 13, 20):
+        wp, t = swarm(40 + m, 18, m)
+        coef, dur, status = ctx9.solve_batch(wp, t)
+        assert (status == 0).all()
+        ref, rdur = _c_ref(wp, t, ncoef=10)
+        assert norm_rel(coef, ref) <= TIGHT9
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            ctx9.set_stream(side.cuda_stream)
+            for m, n in ((16, 18), (20, 5000)):
+                wp, t = swarm(50 + m, n, m)
+                dwp, dt_ = torch.from_numpy(wp).to(dev), torch.from_numpy(t).to(dev)
+                coef = torch.empty((n, m, 4, 10), dtype=torch.float64, device=dev)
+                dur = torch.empty((n, m), dtype=torch.float64, device=dev)
+                status = torch.empty((n,), dtype=torch.int32, device=dev)
+                ctx9.solve_batch_device(n, m, dwp, dt_, False, coef, dur, status)
+                side.synchronize()
+                assert int(status.abs().sum()) == 0
+                ref, _ = _c_ref(wp[:64], t[:64], ncoef=10)
+                assert norm_rel(coef[:64].cpu().numpy(), ref) <= TIGHT9
+    finally:
+        ctx9.use_own_stream()
+
+
 # ---------------------------------------------------------------------------
 # size-independent properties at BASELINE.json's full sizes
 # ---------------------------------------------------------------------------

@@ -25,7 +25,7 @@ lib.msnap_debug_read_grid_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int]
 with Context(0, 7, 64) as ctx:
     ctx.prepare_grid(tgrid)
     for _ in range(20):
-        ctx.solve_grid_device(N, dwp, coef, dur, st)
+        ctx.solve_grid_device(N, M, dwp, coef, dur, st)
     ctx.sync()
     nw = N // 4
     buf = np.zeros((nw, 8), dtype=np.uint64)

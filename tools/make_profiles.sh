@@ -19,11 +19,14 @@ python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err
 echo "== 3. HBM traffic counters, one pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), per workload"
 HEAD="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-saturated --no-shared-grid --no-configs --no-end-to-end"
 SAT="--no-graph --drones 1048576 --steps 5 --warmup 2 --no-cpu-baseline --no-saturated --no-shared-grid --no-configs --no-end-to-end"
+K2="--no-graph --drones 1048576 --saturated-drones 1048576 --steps 5 --warmup 2 --no-cpu-baseline --no-saturated --no-configs --no-end-to-end"
 C4="--no-graph --order 9 --drones 65536 --steps 20 --warmup 5 --no-cpu-baseline --no-saturated --no-shared-grid --no-configs --no-end-to-end"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_65536x10o9_$C -- python3 bench.py $C4 > /dev/null 2> $OUT/pmc_c4_$C.err || { tail -5 $OUT/pmc_c4_$C.err; exit 1; }
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_256x10o7_$C -- python3 bench.py $HEAD > /dev/null 2> $OUT/pmc_h_$C.err || { tail -5 $OUT/pmc_h_$C.err; exit 1; }
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_1048576x10o7_$C -- python3 bench.py $SAT > /dev/null 2> $OUT/pmc_s_$C.err || { tail -5 $OUT/pmc_s_$C.err; exit 1; }
+  # the shared-grid GEMM (K2) at the same size: every grid_gemm launch of this command is 2^20 drones
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_grid1048576x10o7_$C -- python3 bench.py $K2 > /dev/null 2> $OUT/pmc_g_$C.err || { tail -5 $OUT/pmc_g_$C.err; exit 1; }
 done
 echo "== 4. SQ counters (all kernels of the default command: solve variants + the K2 MFMA GEMM)"
 ALL="--no-graph --steps 100 --warmup 10 --no-cpu-baseline --no-end-to-end"

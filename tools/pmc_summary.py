@@ -45,14 +45,16 @@ def main():
     for wl, kernels in per_wl.items():
         if "x" not in wl or "o" not in wl:
             continue
-        cands = {k: c for k, c in kernels.items() if "solve_kernel" in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c}
+        # "<drones>x..": the per-drone solve (K1); "grid<drones>x..": the shared-grid GEMM (K2) of the same batch
+        want = "grid_gemm" if wl.startswith("grid") else "solve_kernel"
+        cands = {k: c for k, c in kernels.items() if want in k and "FETCH_SIZE" in c and "WRITE_SIZE" in c}
         if not cands:
             continue
         name = max(cands, key=lambda k: len(cands[k]["FETCH_SIZE"]))
         c = cands[name]
         fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024.0
         write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024.0
-        drones = int(wl.split("x")[0])
+        drones = int(wl.split("x")[0].replace("grid", ""))
         traffic[wl] = {"kernel": name, "drones": drones, "csrc_sha": csrc_sha(), "fetch_bytes_raw": fetch,
                        "fetch_bytes_corrected_x2": 2 * fetch, "write_bytes": write,
                        "hbm_bytes_per_launch": 2 * fetch + write}
