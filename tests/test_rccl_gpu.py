@@ -50,11 +50,13 @@ def test_formation_pass_through_rccl_on_one_rank(nccl_world1, ctx7, n, mode):
     dist = nccl_world1
     dev = torch.device("cuda", 0)
     wp, t = _swarm(n, 6, 17 + n)
-    S, dt, radius = 31, 0.25, 0.2
+    S, dt = 31, 0.25
     comp = sw.DeviceCompute(ctx7, torch)        # borrows torch's current stream: the collectives order against it
     try:
         coef, dur, status = comp.solve(torch.from_numpy(wp).to(dev), torch.from_numpy(t).to(dev))
         assert int(status.abs().sum()) == 0
+        md0 = sw.formation_pass(comp, coef, dur, n, 1, 0, dt, S, 0.0, torch=torch, status_local=status).min_dist
+        radius = 0.5 * float(md0.median()) * 1.0001      # about half of the swarm collides
         plain = sw.formation_pass(comp, coef, dur, n, 1, 0, dt, S, radius, torch=torch, status_local=status)
         coll = sw.formation_pass(comp, coef, dur, n, 1, 0, dt, S, radius, dist=dist, torch=torch, status_local=status,
                                  force_collectives=True, force_mode=mode)
