@@ -565,14 +565,18 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                           "time grids takes), outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
-            "pairwise": {"kernel": ((("msnap::collide_key_kernel + collide_rank_kernel + collide_transpose_kernel + "
-                                      "collide_bound_kernel + collide_select_kernel + collide_eval_kernel + "
-                                      "collide_resolve_kernel + collide_merge_kernel (exact broad phase; the same arithmetic "
-                                      "on the surviving ") + ("8 x 8 group pairs)" if by_groups else "128 x 8 shares)")
+            "pairwise": {"kernel": (("msnap::" + ("" if world == 1 else "collide_key_kernel + ") + "collide_rank_kernel + "
+                                     "collide_gather_kernel + collide_select_kernel + " +
+                                     ("collide_eval_groups_kernel + collide_finish_groups_kernel (exact broad phase; the pass's "
+                                      "arithmetic on the surviving 8 x 8 group pairs" if by_groups else
+                                      "collide_eval_shares_kernel + collide_merge_kernel (exact broad phase; the pass's "
+                                      "arithmetic on the surviving 128 x 8 shares") +
+                                     ("; boxes and sort keys from the sampler)" if world == 1 else ")")
                                      if broad else
                                      "msnap::collide_span_kernel + collide_merge_kernel (rows from the sampler's image)")
                                     if (world == 1 or whole) else "msnap::collide_transpose_kernel + collide_span_kernel + "
                                     "collide_merge_kernel on this rank's part of the swarm's pairs"),
+                         "launches_per_pass": (5 + (0 if world == 1 else 1)) if broad else (2 if world == 1 else 3),
                          "ranks": (None if world == 1 else
                                    "every rank runs the pass over the whole gathered swarm behind the broad phase and keeps "
                                    "its rows: no second collective (swarm.DeviceCompute.pairwise_mode, decided from the "

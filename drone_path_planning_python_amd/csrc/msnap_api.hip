@@ -18,6 +18,13 @@ int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what) {
   return MSNAP_EHIP;
 }
 
+int handover_form(const msnap_ctx *ctx, const void *ptr, int n, int n_samples) {
+  if (!ptr) return 0;
+  for (const auto &h : ctx->handover)
+    if (h.ptr == ptr) return (h.n == n && h.s == n_samples) ? h.form : 0;
+  return 0;
+}
+
 bool stream_is_capturing(const msnap_ctx *ctx) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   return ctx->stream && hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
@@ -157,6 +164,12 @@ int msnap_create(msnap_ctx **out, int device_id, int order, int max_segments) {
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { rc = MSNAP_EHIP; break; }
     ctx->stream = ctx->own_stream;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) { rc = MSNAP_EHIP; break; }
+    if (hipHostMalloc((void **)&ctx->cull_hint, 64, hipHostMallocDefault) != hipSuccess) {
+      ctx->cull_hint = nullptr;      // (the pairwise pass then never has a hint and keeps its default evaluator)
+      (void)hipGetLastError();
+    } else {
+      *ctx->cull_hint = 0;
+    }
     rc = solve_kernel_setup(ctx);
   } while (0);
   if (rc != MSNAP_OK) {
@@ -186,6 +199,7 @@ void msnap_destroy(msnap_ctx *ctx) {
   }
   if (ctx->pipe_start) (void)hipEventDestroy(ctx->pipe_start);
   if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+  if (ctx->cull_hint) (void)hipHostFree(ctx->cull_hint);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -293,7 +307,7 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
           hipMemcpy(&groups, ctx->collide_meta + MSNAP_COLLIDE_META_GROUPS, sizeof groups, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     }
-    const bool by_groups = culled && collide_counts_by_groups(ctx, shares, groups);
+    const bool by_groups = culled && ctx->collide_last_by_groups;
     if (!strcmp(name, "collide_last_group_pairs")) *value = groups;
     else if (!strcmp(name, "collide_last_survivors")) *value = shares;
     else if (!strcmp(name, "collide_last_by_groups")) *value = by_groups ? 1 : 0;
@@ -635,7 +649,7 @@ int msnap_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *c
   if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
   if (!coef || !dur || !pos) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, n_axes, pos, nullptr);
+  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, n_axes, pos, nullptr, false);
 }
 
 size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples) {
@@ -644,8 +658,9 @@ size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples) {
 }
 
 int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
+  (void)row_offset;
   if (!ctx || n_rows <= 0 || n_cols <= 0 || n_samples < 6) return 0;      // (paths shorter than one sample chunk: plain loops)
-  return formation_collide_takes_broad_phase(ctx, n_rows, row_offset, n_cols, n_samples) ? 0 : 1;
+  return 1;
 }
 
 int msnap_formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples) {
@@ -656,10 +671,14 @@ int msnap_formation_collide_takes_broad_phase(const msnap_ctx *ctx, int n_rows, 
 int msnap_formation_whole_pass_pays(msnap_ctx *ctx, int n_drones, int n_ranks, int *pays) {
   if (!ctx || !pays || n_drones < 0 || n_ranks < 1) return MSNAP_EINVAL;
   *pays = 0;
-  long evaluated = -1;
+  long evaluated = -1, shares = 0, groups = 0;
   int rc = msnap_get_option(ctx, "collide_last_pairs_evaluated", &evaluated);
   if (rc) return rc;
   if (evaluated < 0 || n_drones < 2) return MSNAP_OK;      // the last pass evaluated all pairs: the parts divide them
+  // (what the NEXT whole passes of this swarm evaluate: the evaluator follows these counts from then on)
+  if ((rc = msnap_get_option(ctx, "collide_last_survivors", &shares)) || (rc = msnap_get_option(ctx, "collide_last_group_pairs", &groups)))
+    return rc;
+  evaluated = collide_counts_by_groups(ctx, ctx->collide_last_n, (int)shares, (int)groups) ? groups * 64 : shares * 1024;
   // whole pass on every rank: the sort / bound / select launches + the surviving pairs at about 2/3 of the all-pairs
   // kernel's pace; parts: 1 / n_ranks of all pairs + transposition, merge, fold and the second collective -- the fixed
   // costs of the two sides are about equal (measured at 4096 drones), which leaves the arithmetic
@@ -676,7 +695,15 @@ int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const d
   if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
   if (!coef || !dur || !pos || !pos_t) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, 3, pos, pos_t);
+  // what the pass over these drones as a whole swarm will read: behind the broad phase the boxes and sort keys (the
+  // sampler has the samples in LDS; the pass then needs no key launch), otherwise the transposed row image
+  const bool keys = formation_collide_takes_broad_phase(ctx, n_drones, 0, n_drones, n_samples);
+  msnap_ctx::Handover *rec = nullptr;
+  for (auto &h : ctx->handover)
+    if (h.ptr == (const void *)pos_t) rec = &h;
+  if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
+  *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
+  return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, 3, pos, pos_t, keys);
 }
 
 int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
@@ -696,7 +723,7 @@ int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, co
   MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[2].p, coef, b_coef, hipMemcpyHostToDevice, ctx->stream));
   MSNAP_HIP(ctx, hipMemcpyAsync(ctx->stage[3].p, dur, b_dur, hipMemcpyHostToDevice, ctx->stream));
   rc = launch_sample(ctx, n_drones, n_seg, (const double *)ctx->stage[2].p, (const double *)ctx->stage[3].p,
-                     dt, n_samples, n_axes, (double *)ctx->stage[6].p, nullptr);
+                     dt, n_samples, n_axes, (double *)ctx->stage[6].p, nullptr, false);
   if (rc) return rc;
   MSNAP_HIP(ctx, hipMemcpyAsync(pos, ctx->stage[6].p, b_pos, hipMemcpyDeviceToHost, ctx->stream));
   MSNAP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -146,6 +146,37 @@ __global__ void collide_transpose_kernel(const double *__restrict__ prow, int R,
                                          int ny, int32_t *__restrict__ fill, size_t fill_n, const int32_t *__restrict__ perm,
                                          double *__restrict__ psorted);
 
+// The sort key of the pairwise pass's broad phase (CollideCull below): Morton code of the centre of a drone's path box
+// on a 1 m x 1 m x 4 m lattice (paths are metres; 11 + 11 + 10 bits around the origin, clamped beyond +-1 km: a swarm
+// inside one cell, or far out, sorts arbitrarily and less is culled -- the result does not depend on the order).
+// A drone without a finite sample (lo > hi) gets the largest key and sorts to the end.
+__device__ __forceinline__ unsigned long long spread3(unsigned long long v) {      // 21 bits -> every third bit
+  v &= 0x1fffffull;
+  v = (v | (v << 32)) & 0x1f00000000ffffull;
+  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+  v = (v | (v << 8)) & 0x100f00f00f00f00full;
+  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__device__ __forceinline__ unsigned drone_sort_key(const double (&lo)[3], const double (&hi)[3]) {
+  unsigned long long kk = 0xffffffffull;
+  if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+    const double cell[3] = {1.0, 1.0, 4.0}, half[3] = {1024.0, 1024.0, 512.0};
+    unsigned long long q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double c = floor(0.5 * (lo[k] + hi[k]) / cell[k]) + half[k];
+      c = c < 0.0 ? 0.0 : (c > 2.0 * half[k] - 1.0 ? 2.0 * half[k] - 1.0 : c);
+      q[k] = (unsigned long long)c;
+    }
+    kk = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);      // < 2^32 (z has 10 bits)
+  }
+  return (unsigned)kk;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask);
+
 // Generic form: one thread per (drone, sample), the reference's search loop as it stands.  Used for
 // drones whose durations are not all >= 0 (the search is then not a partition into ranges), for
 // dt == 0 and for paths whose samples do not fit the LDS image of the fast kernel.
@@ -202,7 +233,8 @@ sample_generic_kernel(const double *__restrict__ coef, const double *__restrict_
 template <int NC>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
-              int naxes, int DW, double *__restrict__ pos, double *__restrict__ pos_t, int Rp) {
+              int naxes, int DW, double *__restrict__ pos, double *__restrict__ pos_t, int Rp, double *__restrict__ kbox,
+              unsigned *__restrict__ kkey) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double *sB = smem;                                    // [DW][M + 1] running sums, b_0 = 0
@@ -290,13 +322,59 @@ sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, d
         pos_t[(size_t)sk * Rp + d0 + dl] = sImg[(size_t)dl * per_drone + sk];
       }
     }
+    // third output, for a whole-swarm pass behind the exact broad phase: what collide_key_kernel would compute from
+    // the finished positions -- the box of the drone's finite samples and its sort key -- while the samples sit in
+    // the image: 16 threads per drone (DW <= 16, naxes == 3), folded inside their 16 lanes
+    if (kbox != nullptr) {
+      const int dl = tid >> 4, part = tid & 15;
+      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+      if (dl < nd) {
+        const double *img = sImg + (size_t)dl * per_drone;
+        for (int sq = part; sq < S; sq += 16)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double v = img[(size_t)sq * 3 + k];
+            if (__builtin_isfinite(v)) {
+              lo[k] = v < lo[k] ? v : lo[k];
+              hi[k] = v > hi[k] ? v : hi[k];
+            }
+          }
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double ol = shfl_xor_f64(lo[k], m), oh = shfl_xor_f64(hi[k], m);
+          lo[k] = ol < lo[k] ? ol : lo[k];
+          hi[k] = oh > hi[k] ? oh : hi[k];
+        }
+      if (dl < nd && part == 0) {
+        double *b = kbox + (size_t)(d0 + dl) * 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          b[k] = lo[k];
+          b[3 + k] = hi[k];
+        }
+        kkey[d0 + dl] = drone_sort_key(lo, hi);
+      }
+    }
     __syncthreads();
   }
 }
 
+__global__ void collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box,
+                                   unsigned *__restrict__ key);
+constexpr int kKeyDrones = 4;      // drones (wavefronts) per workgroup of collide_key_kernel
+
+// `pos_t`: the sampler's second output for the pairwise pass (msnap_sample_collide): with `keys_form` the per-drone
+// boxes [N][6] followed by the sort keys [N] (uint32) of a whole-swarm pass behind the broad phase, otherwise the
+// transposed row image
 int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,
-                  int n_samples, int n_axes, double *pos, double *pos_t) {
+                  int n_samples, int n_axes, double *pos, double *pos_t, bool keys_form) {
   const int Rp = (n_drones + kRowBlockRows - 1) / kRowBlockRows * kRowBlockRows;
+  double *kbox = keys_form ? pos_t : nullptr;
+  unsigned *kkey = keys_form ? reinterpret_cast<unsigned *>(pos_t + (size_t)n_drones * 6) : nullptr;
+  if (keys_form) pos_t = nullptr;
   // drones per workgroup: about 256 (piece, axis) threads, within 48 KB of LDS image
   const size_t img_per_drone = (size_t)n_samples * n_axes * sizeof(double);
   int dw = 256 / (n_seg * n_axes);
@@ -310,10 +388,10 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
     if (blocks > (size_t)ctx->n_cu * 64) blocks = (size_t)ctx->n_cu * 64;
     if (ctx->order == 7)
       hipLaunchKernelGGL((sample_kernel<8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
-                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp);
+                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp, kbox, kkey);
     else
       hipLaunchKernelGGL((sample_kernel<10>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, coef, dur, dt,
-                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp);
+                         n_drones, n_seg, n_samples, n_axes, dw, pos, pos_t, Rp, kbox, kkey);
   } else {
     // one drone's samples exceed the image: the (drone, sample) form
     const size_t total = (size_t)n_drones * n_samples;
@@ -331,6 +409,11 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
       hipLaunchKernelGGL(collide_transpose_kernel, dim3(Rp / 64, (E + 31) / 32), dim3(256), 0, ctx->stream,
                          (const double *)pos, n_drones, Rp, E, pos_t, (E + 31) / 32, (int32_t *)nullptr, (size_t)0,
                          (const int32_t *)nullptr, (double *)nullptr);
+    }
+    if (kbox != nullptr) {      // ... or the key pass over the finished positions
+      MSNAP_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(collide_key_kernel, dim3((n_drones + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
+                         ctx->stream, (const double *)pos, n_drones, n_samples, kbox, kkey);
     }
   }
   MSNAP_HIP(ctx, hipGetLastError());
@@ -640,7 +723,6 @@ struct RowSet {
 // those of the full pass, whatever the order and whatever is skipped.
 struct CollideCull {
   const double *colbox;    // [ceil(N / 8)][6] lo x,y,z / hi x,y,z per aligned group of 8 sorted drones
-  const double *cmax;      // [ceil(N / 8)] largest bound of the group
 };
 
 __device__ __forceinline__ double box_box_lb2(const double *__restrict__ a, const double *__restrict__ b) {
@@ -959,6 +1041,9 @@ collide_span_kernel(const double *__restrict__ prow_t, const double *__restrict_
 // part more than the others so that the items are exactly the wave slots changed nothing there and cost a sparse
 // swarm 10 us (its uncut shares become the long poles) -- CullSplit keeps that form, x = 0.
 constexpr int kCullMaxParts = 8;
+constexpr int kCullMaxDrones = 16384;      // largest whole swarm that takes the broad phase (the rank count's words per lane)
+constexpr int kCullMinDrones = 3072;       // smallest, by default ("collide_cull_min_drones")
+constexpr int kCullGroupMaxDrones = 8192;  // largest whose group pairs are all given a list slot (524 800): the group evaluator
 struct CullSplit {
   int lo, hi, x;      // x shares in `hi` parts, the others in `lo`
   __device__ __host__ __forceinline__ int items(int tot) const { return x * hi + (tot - x) * lo; }
@@ -1012,61 +1097,104 @@ enum : int {
 // The second granularity of the broad phase: pairs of GROUPS (8 x 8 drones of the sorted order).  Of a surviving share
 // (128 rows x 8 columns) usually one or two of its 16 row groups are what kept it; the group pairs that pass the same
 // test are a few per cent of all (fixture: 3919 of 131 328, 0.25 M pairs against the surviving shares' 1.43 M).  They
-// are evaluated by collide_eval_kernel (collide_group_body) with the samples across the lanes; the minima meet in
-// per-drone atomics.
+// are evaluated by collide_eval_groups_kernel with the samples across the lanes, every item leaving 16 candidates -- one
+// per row drone and one per column drone.  The selection leaves, besides the list itself, what lets
+// collide_finish_groups_kernel fold a group's candidates without searching: the items of group g as the row side are the
+// contiguous list range [astart[g], + acnt[g]) (the diagonal item (g, g) included), the items (a, g) with g as the column
+// side are the non-zero entries of blist[g][a < g] = list position + 1.
 struct CullGroups {
-  int32_t *glist;                 // [cap] (a << 16 | b), a <= b: surviving group pairs, any order
-  unsigned long long *dmin;       // [N] bit pattern of the smallest squared distance so far (sorted index)
-  int32_t *pmin;                  // [N] lowest ORIGINAL partner index attaining it (collide_resolve_kernel)
+  int32_t *glist;                 // [cap] (a << 16 | b), a <= b: surviving group pairs, a-major, ascending b per a
+  int32_t *astart, *acnt;         // [nG] list range of the items (g, b >= g)
+  int32_t *blist;                 // [nG][nG]: list position + 1 of the item (a, g) at [g][a] (0: none; zeroed per pass)
   double *cand_d2;                // [cap][16] what item `it` found for its 8 row drones and its 8 column drones
   int32_t *cand_j;
-  int cap;                        // list capacity: more surviving group pairs than this take the share path
-  int mode;                       // 0: choose per pass (cull_use_groups), 1: shares, 2: groups (if they fit)
+  int cap;                        // list capacity (all group pairs when this path is taken: it cannot overflow)
+  int nG;
 };
 // Same arithmetic per pair and sample on both paths; the group kernel spends about 2.2 x as many vector instructions per
 // pair-sample (91 samples on 128 lanes, the cross-lane folds), the share kernel runs a single short round at 0.7 of its
 // pace: groups when 64 x 2.2 x (group pairs) < 1024 x 1.45 x (shares).
-__device__ __host__ __forceinline__ bool cull_use_groups(int shares, int groups, const CullGroups &cg) {
-  if (cg.mode == 1 || groups > cg.cap) return false;
-  if (cg.mode == 2) return true;
-  return (long long)groups * 141 < (long long)shares * 1485;
+__device__ __host__ __forceinline__ bool cull_groups_cheaper(long long shares, long long groups) {
+  return groups * 141 < shares * 1485;
+}
+// what a pass leaves for the next one's choice of evaluator (one 64-bit word in page-locked host memory, written by
+// the evaluator's first wave: the host reads it without synchronising): swarm size, surviving shares, surviving
+// group pairs
+__device__ __host__ __forceinline__ unsigned long long cull_hint_pack(int N, int shares, long long groups) {
+  return ((unsigned long long)(N & 0x7fff) << 48) | ((unsigned long long)(shares & 0xffffff) << 24) |
+         (unsigned long long)(groups < 0xffffff ? groups : 0xffffff);
 }
 
 // One workgroup per row block: its threads test the shares (at most 1024 of them: kCullMaxDrones / 8); the survivors are
 // written, in ascending order, to a range of the list that the workgroup reserves with one atomic add -- the row
 // blocks' ranges come in any order, each is contiguous: list[start[I] .. + cnt[I]) = (I << 16 | k).
-constexpr int kSelThreads = 256;
+// (1024 threads: with 256 a wavefront sat alone on its SIMD and walked 32 dependent box tests -- 12 us of an 8-launch
+// pass's shortest chain; sixteen wavefronts per workgroup hide each other's latencies)
+constexpr int kSelThreads = 1024;
 constexpr int kSelGroups = 8;      // group-pair selection: a's per workgroup
-// kSelTrips (template parameter): trips of a workgroup over a row block's shares / a group's partners: 4 up to 8192
-// drones, 8 up to kCullMaxDrones (16 384 / 8 = 8 x kSelThreads)
+// kSelTrips (template parameter): trips of a workgroup over a row block's shares / a group's partners: 1 up to 8192
+// drones, 2 up to kCullMaxDrones (16 384 / 8 = 2 x kSelThreads)
 template <int kSelTrips>
 __global__ void __launch_bounds__(kSelThreads)
-collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ list, int32_t *__restrict__ cnt,
-                      int32_t *__restrict__ meta, CullGroups cg) {
+collide_select_kernel(int N, int n_rb, CollideCull cu, const double *__restrict__ bound, int32_t *__restrict__ list,
+                      int32_t *__restrict__ cnt, int32_t *__restrict__ meta, CullGroups cg) {
+  // Every workgroup first stages what all its tests read: the largest bound of every group of 8 sorted drones (the
+  // bounds were finished by the previous launch: atomic minima of the gather tiles over the sorted neighbours; 0 for a
+  // drone without a finite sample) and -- swarms up to 8192 drones, 56 KB -- the groups' boxes: one memory round trip,
+  // then the box tests run out of LDS.
+  constexpr bool kStage = kSelTrips == 1;
+  constexpr int kStageGroups = kStage ? kCullGroupMaxDrones / kColBlock : 1;
+  __shared__ double sCmax[kCullMaxDrones / kColBlock];
+  __shared__ double sBox[kStageGroups * 6];
+  {
+    const int nG = (N + kColBlock - 1) / kColBlock;
+    for (int gq = threadIdx.x; gq < nG; gq += kSelThreads) {
+      double m = 0.0;
+#pragma unroll
+      for (int d = 0; d < kColBlock; ++d) {
+        const int r = gq * kColBlock + d;
+        m = fmax(m, bound[r < N ? r : N - 1]);
+      }
+      sCmax[gq] = m;
+    }
+    if constexpr (kStage)
+      for (int e = threadIdx.x; e < nG * 6; e += kSelThreads) sBox[e] = cu.colbox[e];
+    __syncthreads();
+  }
+  auto load_box = [&](int gq, double(&B)[6]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if constexpr (kStage) B[k] = sBox[gq * 6 + k];
+      else B[k] = cu.colbox[(size_t)gq * 6 + k];
+    }
+  };
   if ((int)blockIdx.x >= n_rb) {
     // group pairs (a, b), a <= b: a workgroup takes kSelGroups a's and tests each against every b (the same strict test
     // on the two groups' boxes and bounds); its survivors are appended with ONE atomic reservation -- a reservation per
     // a was 512 atomics on one word, 20 ns apiece -- the workgroups in no particular order
     constexpr int NW = kSelThreads / kWave, NS = kSelGroups * kSelTrips;
     __shared__ int gsum[NS * NW + 1];
-    __shared__ int gbase;
+    __shared__ int gbase, gtot;
     const int a0 = (blockIdx.x - n_rb) * kSelGroups, nG = (N + kColBlock - 1) / kColBlock;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     unsigned long long kept = 0;      // bit (ai * kSelTrips + t): pair (a0 + ai, a + t * kSelThreads + thread) survives
 #pragma unroll
     for (int ai = 0; ai < kSelGroups; ++ai) {
       const int a = a0 + ai;
-      double A[7];
+      double A[7], A6[6];
+      load_box(a < nG ? a : nG - 1, A6);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) A[k] = cu.colbox[(size_t)(a < nG ? a : nG - 1) * 6 + k];
-      A[6] = cu.cmax[a < nG ? a : nG - 1];
+      for (int k = 0; k < 6; ++k) A[k] = A6[k];
+      A[6] = sCmax[a < nG ? a : nG - 1];
 #pragma unroll
       for (int t = 0; t < kSelTrips; ++t) {      // (at most kCullMaxDrones / 8 groups)
         bool keep = false;
         if (a + t * kSelThreads < nG) {      // (wave-uniform)
           const int b = a + t * kSelThreads + threadIdx.x, bc = b < nG ? b : nG - 1;
-          const double lb2 = box_box_lb2(A, cu.colbox + (size_t)bc * 6);
-          keep = b < nG && (b == a || !((lb2 > A[6]) & (lb2 > cu.cmax[bc])));
+          double B6[6];
+          load_box(bc, B6);
+          const double lb2 = box_box_lb2(A, B6);
+          keep = b < nG && (b == a || !((lb2 > A[6]) & (lb2 > sCmax[bc])));
         }
         const unsigned long long m = __ballot(keep);
         kept |= keep ? 1ull << (ai * kSelTrips + t) : 0ull;
@@ -1088,9 +1216,19 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
         if (i0 + lane < NS * NW) gsum[i0 + lane] = run + inc - v;
         run += __shfl(inc, kWave - 1);
       }
-      if (lane == 0) gbase = atomicAdd(&meta[kMetaGroups], run);
+      if (lane == 0) {
+        gbase = atomicAdd(&meta[kMetaGroups], run);
+        gtot = run;
+      }
     }
     __syncthreads();
+    // the survivors of one a are contiguous (a-major order): its row-side range for the evaluator's finish
+    if (threadIdx.x < kSelGroups && a0 + (int)threadIdx.x < nG) {
+      const int ai = threadIdx.x;
+      const int s0 = gsum[ai * kSelTrips * NW], s1 = ai + 1 < kSelGroups ? gsum[(ai + 1) * kSelTrips * NW] : gtot;
+      cg.astart[a0 + ai] = gbase + s0;
+      cg.acnt[a0 + ai] = s1 - s0;
+    }
 #pragma unroll
     for (int ai = 0; ai < kSelGroups; ++ai)
 #pragma unroll
@@ -1098,7 +1236,11 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
         const bool keep = (kept >> (ai * kSelTrips + t)) & 1ull;
         const unsigned long long m = __ballot(keep);
         const int pos = gbase + gsum[(ai * kSelTrips + t) * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && pos < cg.cap) cg.glist[pos] = ((a0 + ai) << 16) | (a0 + ai + t * kSelThreads + threadIdx.x);
+        if (keep && pos < cg.cap) {
+          const int a = a0 + ai, b = a + t * kSelThreads + threadIdx.x;
+          cg.glist[pos] = (a << 16) | b;
+          if (b != a) cg.blist[(size_t)b * cg.nG + a] = pos + 1;      // the column side's reverse list (0: none)
+        }
       }
     return;
   }
@@ -1113,7 +1255,7 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
   const int ng = nsh < GPB ? nsh : GPB;
   if (threadIdx.x < 7 * GPB) {
     const int q = threadIdx.x / 7, k = threadIdx.x % 7;
-    if (q < ng) sRow[q][k] = k < 6 ? cu.colbox[(size_t)(I * GPB + q) * 6 + k] : cu.cmax[I * GPB + q];
+    if (q < ng) sRow[q][k] = k < 6 ? (kStage ? sBox[(I * GPB + q) * 6 + k] : cu.colbox[(size_t)(I * GPB + q) * 6 + k]) : sCmax[I * GPB + q];
   }
   __syncthreads();
   // the union of the row block's groups: a share that fails against it fails against every group (most do, and whole
@@ -1133,9 +1275,8 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, int32_t *__restrict__ lis
   for (int t = 0; t < kSelTrips; ++t) {
     if (t * kSelThreads >= nsh) continue;      // (workgroup-uniform)
     const int k = t * kSelThreads + threadIdx.x, J = I * GPB + (k < nsh ? k : nsh - 1);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) cbx[t][c] = cu.colbox[(size_t)J * 6 + c];
-    cmx[t] = cu.cmax[J];
+    load_box(J, cbx[t]);
+    cmx[t] = sCmax[J];
   }
 #pragma unroll
   for (int t = 0; t < kSelTrips; ++t) {
@@ -1249,27 +1390,118 @@ collide_span_list_body(const double *__restrict__ prow_t, const double *__restri
 // drones' positions come as coalesced loads of the sorted drone-major copy, no scalar or LDS operand traffic.  After the
 // samples a reduce-scatter butterfly inside each half (32 -> 16 -> ... -> 1 value per lane, halving the lane span each
 // time) leaves pair (r, c) = ((lane >> 2) & 7, lane & 3) of the half in its lane; row-side (over c, then over the halves)
-// and column-side (over r) candidates follow with lexicographic (distance, ORIGINAL index) folds.  Each candidate goes
-// to the item's slot and, as a bit pattern (squared distances are non-negative doubles: ordered like their patterns),
-// into an atomic minimum per drone; collide_resolve_kernel then lets the candidates that equal their drone's minimum bid
-// for the lowest partner.
+// and column-side (over r) candidates follow with lexicographic (distance, ORIGINAL index) folds and go to the item's
+// 16 candidate slots.
 constexpr int kGroupHalf = kColBlock / 2;
-constexpr int kGroupCap = 1 << 18;      // group pairs the list holds (all 131 328 of 4096 drones; 8192 have 524 800)
 constexpr int kGroupLanes = kWave / 2;  // samples per trip
-__device__ __forceinline__ void
-collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t *__restrict__ oid,
-                   const int32_t *__restrict__ meta, const CullGroups &cg) {
+
+// The pass's last launch on the group path: one wavefront per group of 8 sorted drones folds the candidates of all the
+// group's items -- row-side slots of the items (g, b) (a contiguous list range), column-side slots of the items (a, g)
+// (the non-zero entries of the group's reverse-list row, fetched in one flight and compacted through LDS) -- a lane per
+// item, then across the lanes drone by drone: the minimum, and the lowest ORIGINAL partner index among the lanes that hold
+// it (as in the all-pairs pass); distance, partner and hit leave through the sort permutation.
+// (Built first as the tail of the evaluator -- the wave completing a group's last item, found by an arrival counter,
+// finished the group: 36 us where evaluator + this launch take 27.  Inside one launch the candidates cross XCDs through
+// device-coherent stores the writer has to wait for, a returning atomic and coherent loads: five memory-side round trips
+// of ~2 us behind every item, against one kernel boundary.)
+constexpr int kFinishWaves = 4;      // groups (wavefronts) per workgroup
+__global__ void __launch_bounds__(kWave * kFinishWaves)
+collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, CullGroups cg, double radius,
+                             double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
+  constexpr int kChunks = kCullGroupMaxDrones / kColBlock / kWave;
+  __shared__ int sItAll[kFinishWaves][kChunks * kWave];
+  const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  int *sIt = sItAll[w];
+  const int gq = blockIdx.x * kFinishWaves + w;
+  if (gq >= cg.nG) return;
+  int pl[kChunks];
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c)
+    pl[c] = (c * kWave < gq && c * kWave + lane < gq) ? cg.blist[(size_t)gq * cg.nG + c * kWave + lane] : 0;
+  const int nA = cg.acnt[gq], sA = cg.astart[gq];
+  // lane = 8 e + k: entry slot e, drone k of the group
+  const int k = lane & (kColBlock - 1), e = lane >> 3;
+  const int r = gq * kColBlock + k;
+  const int out = r < N ? oid[r] : 0;      // (fetched under the candidates)
+  int nB = 0;
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const unsigned long long m = __ballot(pl[c] > 0);      // (0 behind the group's own row)
+    if (pl[c] > 0) {
+      sIt[nB + __popcll(m & ((1ull << lane) - 1ull))] = pl[c] - 1;
+      cg.blist[(size_t)gq * cg.nG + c * kWave + lane] = 0;      // the row is left clean for the next pass
+    }
+    nB += __popcll(m);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  double best = INFINITY;
+  int bj = -1;
+  constexpr int U = 4;      // entries of a lane in flight: 32 items of the group per round
+  for (int q0 = 0; q0 < nA + nB; q0 += U * (kWave / kColBlock)) {
+    double d[U];
+    int j[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + u * (kWave / kColBlock) + e;
+      d[u] = INFINITY;
+      j[u] = -1;
+      if (q < nA + nB) {
+        const size_t slot = (q < nA ? (size_t)(sA + q) * 16 : (size_t)sIt[q - nA] * 16 + kColBlock) + k;
+        d[u] = cg.cand_d2[slot];
+        j[u] = cg.cand_j[slot];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (j[u] >= 0 && (bj < 0 || d[u] < best || (d[u] == best && j[u] < bj))) {
+        best = d[u];
+        bj = j[u];
+      }
+  }
+  // the eight entry lanes of a drone folded: lowest distance, then lowest ORIGINAL partner index
+#pragma unroll
+  for (int m = kColBlock; m < kWave; m <<= 1) {
+    const double o = shfl_xor_f64(best, m);
+    const int oj = __shfl_xor(bj, m);
+    if (oj >= 0 && (bj < 0 || o < best || (o == best && oj < bj))) {
+      best = o;
+      bj = oj;
+    }
+  }
+  if (e == 0 && r < N) {
+    const double dist = sqrt(bj >= 0 ? best : INFINITY);
+    min_dist[out] = dist;
+    partner[out] = bj;
+    hit[out] = (dist < 2.0 * radius) ? 1 : 0;
+  }
+}
+
+// The evaluator of the surviving group pairs: a fixed grid of waves walks the list, one item per wave slot at the
+// fixture's 3919 survivors; collide_finish_groups_kernel follows.
+constexpr int kGroupWaves = 4;      // waves per SIMD the group evaluator is built for (128 registers)
+__global__ void __launch_bounds__(kWave, kGroupWaves)
+collide_eval_groups_kernel(const double *__restrict__ pcol, int N, int S, const int32_t *__restrict__ oid,
+                           const int32_t *__restrict__ meta, CullGroups cg, unsigned long long *__restrict__ hint) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x;
   const int tot = meta[kMetaGroups];
+  if (blockIdx.x == 0 && lane == 0 && hint != nullptr)
+    __hip_atomic_store(hint, cull_hint_pack(N, meta[kMetaTotal], tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const unsigned stride = (unsigned)S * 3u;
-  const int half = lane >> 5, ls = lane & (kGroupLanes - 1);
-  // this lane's pair after the butterfly
-  const int pr = ls >> 2, pc = ls & (kGroupHalf - 1);
+  // (the first list entry is fetched beside the survivor count, the next one under the current item)
+  int entry = (int)blockIdx.x < cg.cap ? cg.glist[blockIdx.x] : 0;
   for (int it = blockIdx.x; it < tot; it += gridDim.x) {
-    const int entry = cg.glist[it];
     const int a = entry >> 16, b = entry & 0xffff;
     const bool diag = a == b;
+    entry = it + (int)gridDim.x < tot ? cg.glist[it + gridDim.x] : 0;
+
+    // (everything derived from the lane index is rebuilt per phase from an opaque copy: left visible, the values the
+    // candidate folds need are computed up front and held through the sample loop, whose 128 registers are spoken for)
+    int lane_s = threadIdx.x;
+    asm volatile("" : "+v"(lane_s));
+    const int half = lane_s >> 5, ls = lane_s & (kGroupLanes - 1);
     double acc[kColBlock * kGroupHalf];
 #pragma unroll
     for (int p = 0; p < kColBlock * kGroupHalf; ++p) acc[p] = INFINITY;
@@ -1294,14 +1526,17 @@ collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t 
 #pragma unroll
         for (int c = 0; c < kGroupHalf; ++c) {
           const double dx = cx[c] - x, dy = cy[c] - y, dz = cz[c] - z;
-          acc[r * kGroupHalf + c] = __builtin_fmin(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), acc[r * kGroupHalf + c]);
+          const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
+          // (the minimum by hand, as in collide_block: fmin would canonicalise the accumulator with a v_max first --
+          // an eighth instruction per pair and sample; a quiet NaN loses either way)
+          asm("v_min_f64 %0, %1, %0" : "+v"(acc[r * kGroupHalf + c]) : "v"(d2));
         }
       }
     }
     // reduce-scatter over the 32 lanes of the half: 32 values per lane -> 1, pair p = lane & 31
 #pragma unroll
     for (int n = 16, m = 16; n >= 1; n >>= 1, m >>= 1) {
-      const bool up = (lane & m) != 0;
+      const bool up = (lane_s & m) != 0;
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         const double keep = up ? acc[i + n] : acc[i], send = up ? acc[i] : acc[i + n];
@@ -1309,7 +1544,11 @@ collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t 
       }
     }
     double v = acc[0];
-    const int ra = a * kColBlock + pr, cb = b * kColBlock + half * kGroupHalf + pc;
+    // this lane's pair after the butterfly
+    int lane_c = threadIdx.x;
+    asm volatile("" : "+v"(lane_c));
+    const int pr = (lane_c & (kGroupLanes - 1)) >> 2, pc = lane_c & (kGroupHalf - 1), half_c = lane_c >> 5;
+    const int ra = a * kColBlock + pr, cb = b * kColBlock + half_c * kGroupHalf + pc;
     const int oi = oid[ra < N ? ra : N - 1], oj = oid[cb < N ? cb : N - 1];
     if (ra >= N || cb >= N || (diag && ra == cb)) v = INFINITY;
     // row side: over the 4 columns of the half (lane bits 0, 1), then over the halves (bit 5)
@@ -1325,10 +1564,8 @@ collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t 
         wj = take ? ojx : wj;
       }
       if ((lane & 35) == 0) {      // half 0, pc == 0: lane = 4 pr
-        const bool have = w < INFINITY;
         cg.cand_d2[(size_t)it * 16 + pr] = w;
-        cg.cand_j[(size_t)it * 16 + pr] = have ? wj : -1;
-        if (have) atomicMin(&cg.dmin[ra], (unsigned long long)__double_as_longlong(w));
+        cg.cand_j[(size_t)it * 16 + pr] = w < INFINITY ? wj : -1;
       }
     }
     // column side: over the 8 rows (lane bits 2..4); the diagonal group's columns are its rows
@@ -1343,44 +1580,25 @@ collide_group_body(const double *__restrict__ pcol, int N, int S, const int32_t 
         w = take ? o : w;
         wi = take ? oix : wi;
       }
-      if (ls < kGroupHalf) {      // pr == 0: lane = 32 half + pc
-        const int k = kColBlock + half * kGroupHalf + pc;
-        const bool have = !diag && w < INFINITY;
+      if ((lane_c & (kGroupLanes - 1)) < kGroupHalf) {      // pr == 0: lane = 32 half + pc
+        const int k = kColBlock + half_c * kGroupHalf + pc;
         cg.cand_d2[(size_t)it * 16 + k] = w;
-        cg.cand_j[(size_t)it * 16 + k] = have ? wi : -1;
-        if (have) atomicMin(&cg.dmin[cb], (unsigned long long)__double_as_longlong(w));
+        cg.cand_j[(size_t)it * 16 + k] = (!diag && w < INFINITY) ? wi : -1;
       }
     }
   }
 }
 
-// The evaluator behind the broad phase: ONE launch of a fixed grid of waves that reads the two survivor counts and walks
-// either the surviving shares or the surviving group pairs (cull_use_groups).
+// The evaluator of the surviving shares (collide_span_list_body above); collide_merge_kernel follows it.
 __global__ void __launch_bounds__(kWave, 4)
-collide_eval_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
-                    double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
-                    int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
-                    int sp_force, int slots, int32_t *__restrict__ meta, CullGroups cg) {
-  if (cull_use_groups(meta[kMetaTotal], meta[kMetaGroups], cg))
-    collide_group_body(pcol, g.R, g.S, oid, meta, cg);
-  else
-    collide_span_list_body(prow_t, pcol, g, part_d2, part_j, cpart_d2, cpart_i, oid, list, sp_force, slots, meta);
-}
-
-// Every candidate that equals its drone's minimum bids for the partner: the lowest ORIGINAL index wins, as in the
-// all-pairs pass (ties between equidistant neighbours).
-__global__ void __launch_bounds__(256)
-collide_resolve_kernel(int N, const int32_t *__restrict__ meta, CullGroups cg) {
-  const int tot = meta[kMetaGroups];
-  if (!cull_use_groups(meta[kMetaTotal], tot, cg)) return;
-  const long long n = (long long)tot * 16;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int j = cg.cand_j[i];
-    if (j < 0) continue;
-    const int entry = cg.glist[i >> 4], k = (int)(i & 15);
-    const int d = k < kColBlock ? (entry >> 16) * kColBlock + k : (entry & 0xffff) * kColBlock + (k - kColBlock);
-    if ((unsigned long long)__double_as_longlong(cg.cand_d2[i]) == cg.dmin[d]) atomicMin(&cg.pmin[d], j);
-  }
+collide_eval_shares_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
+                           double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
+                           int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
+                           int sp_force, int slots, int32_t *__restrict__ meta, unsigned long long *__restrict__ hint) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && hint != nullptr)
+    __hip_atomic_store(hint, cull_hint_pack(g.R, meta[kMetaTotal], meta[kMetaGroups]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  collide_span_list_body(prow_t, pcol, g, part_d2, part_j, cpart_d2, cpart_i, oid, list, sp_force, slots, meta);
 }
 
 // paths shorter than one sample chunk: plain loops, one-sided
@@ -1434,23 +1652,7 @@ __global__ void __launch_bounds__(kMergeRows * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
                      double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit,
-                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta,
-                     CullGroups cg) {
-  if (cnt && cull_use_groups(meta[kMetaTotal], meta[kMetaGroups], cg)) {
-    // the pass was evaluated group pair by group pair: the per-drone atomics hold the result
-    if (threadIdx.x < kMergeRows) {
-      const int r = blockIdx.x * kMergeRows + threadIdx.x;
-      if (r < g.R) {
-        const double best = __longlong_as_double((long long)cg.dmin[r]);
-        const int out = oid[r];
-        const double dist = sqrt(best);
-        min_dist[out] = dist;
-        partner[out] = best < INFINITY ? cg.pmin[r] : -1;
-        hit[out] = (dist < 2.0 * radius) ? 1 : 0;
-      }
-    }
-    return;
-  }
+                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta) {
   __shared__ double sD[kMergeParts][kMergeRows];
   __shared__ int sJ[kMergeParts][kMergeRows];
   const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
@@ -1612,30 +1814,14 @@ __device__ __forceinline__ double uniform_f64(double v) {
 // ------------------------------------------------------------------------------------
 // The exact broad phase of a whole-swarm pass (CollideCull above): sort keys, sort, bounds and boxes.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long spread3(unsigned long long v) {      // 21 bits -> every third bit
-  v &= 0x1fffffull;
-  v = (v | (v << 32)) & 0x1f00000000ffffull;
-  v = (v | (v << 16)) & 0x1f0000ff0000ffull;
-  v = (v | (v << 8)) & 0x100f00f00f00f00full;
-  v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-  v = (v | (v << 2)) & 0x1249249249249249ull;
-  return v;
-}
 
 // per drone (one wavefront each, four to a workgroup: the drone's S x 3 doubles are one coalesced sweep): the box of its
-// finite samples (lo = +inf, hi = -inf when it has none) and the sort key -- the Morton code of the box's centre on a
-// 1 m x 1 m x 4 m lattice (paths are metres; 11 + 11 + 10 bits around the origin, clamped beyond +-1 km: a swarm inside
-// one cell, or far out, sorts arbitrarily and less is culled -- the result does not depend on the order).  Drones
-// without a finite sample get the largest key and sort to the end.
-constexpr int kKeyDrones = 4;
+// finite samples (lo = +inf, hi = -inf when it has none) and the sort key (drone_sort_key).  Only for callers whose
+// positions do not come from this library's sampler -- msnap_sample_collide_device computes both while the samples sit
+// in its LDS image.
 __global__ void __launch_bounds__(kWave * kKeyDrones)
-collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key,
-                   int32_t *__restrict__ meta) {
+collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box, unsigned *__restrict__ key) {
   const int lane = threadIdx.x & (kWave - 1);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {      // (the selection adds its survivors)
-    meta[kMetaTotal] = 0;
-    meta[kMetaGroups] = 0;
-  }
   const int d = blockIdx.x * kKeyDrones + __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   if (d >= N) return;
   const double *p = pos + (size_t)d * S * 3;
@@ -1667,21 +1853,7 @@ collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restr
     box[(size_t)d * 6 + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lo[2];
     box[(size_t)d * 6 + 3 + lane] = lane == 0 ? hi[0] : lane == 1 ? hi[1] : hi[2];
   }
-  if (lane == 0) {
-    unsigned long long kk = 0xffffffffull;
-    if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
-      const double cell[3] = {1.0, 1.0, 4.0}, half[3] = {1024.0, 1024.0, 512.0};
-      unsigned long long q[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        double c = floor(0.5 * (lo[k] + hi[k]) / cell[k]) + half[k];
-        c = c < 0.0 ? 0.0 : (c > 2.0 * half[k] - 1.0 ? 2.0 * half[k] - 1.0 : c);
-        q[k] = (unsigned long long)c;
-      }
-      kk = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);      // < 2^32 (z has 10 bits)
-    }
-    key[d] = (unsigned)kk;
-  }
+  if (lane == 0) key[d] = drone_sort_key(lo, hi);
 }
 
 // The sort, as a rank count spread over the chip: drones are ordered by (key, index) -- all distinct -- so the sorted
@@ -1691,16 +1863,34 @@ collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restr
 // (scalar unit), the sixteen wavefronts' counts are added through LDS.  N^2 / 64 vector compares -- 260 k at 4096
 // drones -- over 256 workgroups; counting in the lanes (a compare and an add-with-carry per pair, 64 drones per
 // workgroup) took 8-10 us, a 78-stage bitonic network in one workgroup 36 us.
-// perm[sorted position] = original index.
-constexpr int kCullMaxDrones = 16384;
-constexpr int kCullMinDrones = 3072;
+// perm[sorted position] = original index.  The kernel is also the pass's first launch: it zeroes the counters the later
+// launches add to (survivor totals, per-group item counts and arrivals) and starts every drone's BOUND -- a squared
+// distance the drone is known to attain, lowered by the gather tiles with atomic minima -- at +inf, or at 0 for a drone
+// without a finite sample (its own result is +inf / -1 whatever is evaluated, it is invisible to the others, and it
+// must not keep its group from being culled).
 constexpr int kRankWaves = 16;
 constexpr int kRankTile = 16;
 // kRankKeys (template parameter): words per lane, N / 1024 rounded up to 4, 8 or 16 (kCullMaxDrones)
 template <int kRankKeys>
 __global__ void __launch_bounds__(kWave * kRankWaves)
-collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict__ perm) {
+collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict__ perm, const double *__restrict__ box,
+                    unsigned long long *__restrict__ bound, int32_t *__restrict__ zero, int n_zero,
+                    int32_t *__restrict__ meta) {
   __shared__ int cnt[kRankWaves][kRankTile];
+  // (a tile drone's box is fetched up front: it only decides where the drone's bound starts)
+  bool has = false;
+  if (threadIdx.x < kRankTile && (int)(blockIdx.x * kRankTile + threadIdx.x) < N) {
+    const double *bx = box + (size_t)(blockIdx.x * kRankTile + threadIdx.x) * 6;
+    has = (bx[0] <= bx[3]) & (bx[1] <= bx[4]) & (bx[2] <= bx[5]);
+  }
+  {
+    const int gid = blockIdx.x * (kWave * kRankWaves) + threadIdx.x;
+    for (int z = gid; z < n_zero; z += gridDim.x * (kWave * kRankWaves)) zero[z] = 0;
+    if (gid == 0) {      // (the selection adds its survivors)
+      meta[kMetaTotal] = 0;
+      meta[kMetaGroups] = 0;
+    }
+  }
   const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nq = (N + kRankWaves * kWave - 1) / (kRankWaves * kWave);      // words per lane
   unsigned long long mine[kRankKeys];
@@ -1728,115 +1918,112 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
     int r = 0;
 #pragma unroll
     for (int q = 0; q < kRankWaves; ++q) r += cnt[q][threadIdx.x];
-    perm[r] = i0 + threadIdx.x;
+    const int i = i0 + threadIdx.x;
+    perm[r] = i;
+    bound[r] = has ? 0x7ff0000000000000ull : 0ull;
   }
 }
 
-// One workgroup (1024 threads: 64 rows x 16 sample groups) per 64 drones of the SORTED order.  For sorted drone r:
-//   bound[r]  = min over its sorted neighbours r +- 1..4 and 32 of the common samples (every ceil(S / 32)-th) of the
-//               pass's own squared distance (fma(dz, dz, fma(dy, dy, dx dx)); non-finite samples never win): a value
-//               the drone's final minimum cannot exceed -- ANY subset of its pair-samples bounds it, which is also why
-//               the pairs across a workgroup boundary are simply left out.  Each pair (r, r + k) is evaluated by its
-//               lower row.  A drone without a finite sample contributes 0 to the maxima below (its own result is
-//               +inf / -1 whatever is evaluated, and it is invisible to the others).
-//   colbox[J], cmax[J]      per aligned group of 8 drones: union of their boxes, largest of their bounds
-// A wavefront is one sample group: two samples, 30 loads, all in flight at once -- the kernel is load latency.
-constexpr int kBoundRows = 64;
-constexpr int kBoundGroups = 16;
-constexpr int kBoundReach = 4;
-__global__ void __launch_bounds__(kBoundRows * kBoundGroups)
-collide_bound_kernel(const double *__restrict__ prow_t, int Rp, int N, int S, const double *__restrict__ box,
-                     const int32_t *__restrict__ perm, double *__restrict__ colbox, double *__restrict__ cmax,
-                     unsigned long long *__restrict__ dmin, int32_t *__restrict__ pmin) {
+// The pass's second launch, three kinds of workgroups behind the sort:
+//  * TILES (64 sorted rows x 5 samples, through LDS, as collide_transpose_kernel): the sorted row image
+//    [sample][xyz][row] and the sorted drone-major copy from one read of pos through the permutation -- and, while the
+//    tile (with the 4 rows behind it) sits in LDS, the drones' BOUNDS: for sorted drone r the minimum over its sorted
+//    neighbours r +- 1..4 and the tile's samples of the pass's own squared distance (fma(dz, dz, fma(dy, dy, dx dx));
+//    non-finite samples never win), folded into bound[r] with an atomic minimum on the bit pattern (squared distances
+//    are non-negative doubles: ordered like their patterns).  ANY subset of a drone's pair-samples bounds its final
+//    minimum from above; with every tile contributing, all samples and the pairs across tile boundaries count.
+//  * BOXES: per aligned group of 8 sorted drones the union of their path boxes (the group's bound is the maximum of
+//    its drones' bounds, formed by the selection once the atomics are complete).
+//  * FILL: the column-side partner slots of the share evaluator marked empty (share path only).
+#ifndef MSNAP_TILE_E
+#define MSNAP_TILE_E 15      // (tools: A/B builds; 4096 x 91: 33 -> 55.5 us per pass, 24 -> 54.1, 18 -> 53.1, 15 -> 52.7, 12 -> 52.4, 9 -> 52.6)
+#endif
+constexpr int kTileE = MSNAP_TILE_E, kTileRows = 64, kTileHalo = 4;
+constexpr int kTilePitch = kTileE + 1 + (kTileE & 1);      // an odd number of doubles: conflict-free columns (33 -> 35)
+static_assert(kTileE % 3 == 0, "whole samples per tile");
+constexpr int kBoxGroups = 32;      // groups per BOXES workgroup: 8 lanes each
+__global__ void __launch_bounds__(256)
+collide_gather_kernel(const double *__restrict__ pos, int N, int Rp, int E, double *__restrict__ prow_t,
+                      double *__restrict__ psorted, const int32_t *__restrict__ perm, unsigned long long *__restrict__ bound,
+                      const double *__restrict__ box, double *__restrict__ colbox, int nx, int ny, int n_box,
+                      int32_t *__restrict__ fill, size_t fill_n) {
 #pragma clang fp contract(off)
-  static_assert(kBoundRows == kWave, "a sample group is one wavefront");
-  __shared__ double sf[kBoundReach][kBoundGroups][kBoundRows];
-  __shared__ double sF[kBoundReach][kBoundRows];
-  const int t = threadIdx.x & (kBoundRows - 1), sg = __builtin_amdgcn_readfirstlane(threadIdx.x / kBoundRows);
-  const int r = blockIdx.x * kBoundRows + t;
-  const bool live = r < N;
-  const int rc = live ? r : N - 1;
-  // the drone's box, for the last step: fetched first, it arrives under the sample loads
-  double g8[7];
-  if (sg == 0) {
-    if (live) {      // the per-drone atomics of the group-pair path (CullGroups)
-      dmin[r] = 0x7ff0000000000000ull;      // +inf
-      pmin[r] = 0x7fffffff;
-    }
-    const int o = perm[rc];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) g8[k] = box[(size_t)o * 6 + k];
+  __shared__ double tile[(kTileRows + kTileHalo) * kTilePitch];
+  __shared__ double sF[kTileHalo][kTileRows];
+  const int tid = threadIdx.x;
+  const int nb = (int)blockIdx.x - nx * ny;
+  if (nb >= n_box) {
+    const size_t stride = (size_t)(gridDim.x - nx * ny - n_box) * 256;
+    for (size_t i = (size_t)(nb - n_box) * 256 + tid; i < fill_n; i += stride) fill[i] = -1;
+    return;
   }
-  const int stride = (S + 2 * kBoundGroups - 1) / (2 * kBoundGroups);
-  double f[kBoundReach];
+  if (nb >= 0) {
+    const int gq = nb * kBoxGroups + (tid >> 3), r = gq * kColBlock + (tid & 7);
+    double g6[6];
 #pragma unroll
-  for (int k = 0; k < kBoundReach; ++k) f[k] = INFINITY;
-  double p[2][kBoundReach + 1][3];
+    for (int k = 0; k < 6; ++k) g6[k] = k < 3 ? INFINITY : -INFINITY;
+    if (r < N) {
+      const double *bx = box + (size_t)perm[r] * 6;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int sq = (sg + i * kBoundGroups) * stride;
-    sq = sq < S ? sq : S - 1;      // (a sample seen twice does not change a minimum)
-    const double *px = prow_t + (size_t)sq * 3 * Rp;
-#pragma unroll
-    for (int k = 0; k <= kBoundReach; ++k) {
-      const int q = rc + k < N ? rc + k : N - 1;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) p[i][k][c] = px[(size_t)c * Rp + q];
+      for (int k = 0; k < 6; ++k) g6[k] = bx[k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      auto fold = [k](double a, double c) { return k < 3 ? fmin(a, c) : fmax(a, c); };
+      g6[k] = fold(g6[k], dpp_f64<0xB1>(g6[k]));      // lane xor 1
+      g6[k] = fold(g6[k], dpp_f64<0x4E>(g6[k]));      // lane xor 2
+      g6[k] = fold(g6[k], dpp_f64<0x141>(g6[k]));     // mirror inside the half-row of 8
+    }
+    if ((tid & 7) == 0 && gq * kColBlock < N) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) colbox[(size_t)gq * 6 + k] = g6[k];
+    }
+    return;
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int k = 1; k <= kBoundReach; ++k) {
-      const double dx = p[i][k][0] - p[i][0][0], dy = p[i][k][1] - p[i][0][1], dz = p[i][k][2] - p[i][0][2];
-      const double d2 = __builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx));
-      f[k - 1] = __builtin_fmin((live && r + k < N) ? d2 : INFINITY, f[k - 1]);
-    }
-#pragma unroll
-  for (int k = 0; k < kBoundReach; ++k) sf[k][sg][t] = f[k];
-  __syncthreads();
-  if (sg < kBoundReach) {      // wavefront k folds the pairs (r, r + k + 1) over the sample groups
-    double v = sf[sg][0][t];
-#pragma unroll 4
-    for (int q = 1; q < kBoundGroups; ++q) v = __builtin_fmin(v, sf[sg][q][t]);
-    sF[sg][t] = v;
+  const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
+  const int r0 = bx * kTileRows, e0 = by * kTileE;
+  const int ne = E - e0 < kTileE ? E - e0 : kTileE;      // whole samples: E and kTileE are multiples of 3
+  for (int idx = tid; idx < (kTileRows + kTileHalo) * kTileE; idx += 256) {
+    const int i = idx / kTileE, tx = idx - i * kTileE;
+    const int r = r0 + i < N ? r0 + i : N - 1;
+    const double v = tx < ne ? pos[(size_t)perm[r] * E + e0 + tx] : 0.0;
+    tile[i * kTilePitch + tx] = v;
+    if (i < kTileRows && tx < ne && r0 + i < N) psorted[(size_t)r * E + e0 + tx] = v;
   }
   __syncthreads();
-  if (sg == 0) {      // (one whole wavefront from here on)
+  {
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int i = ty; i < ne; i += 4) prow_t[(size_t)(e0 + i) * Rp + r0 + tx] = tile[tx * kTilePitch + i];
+  }
+  {
+    // pair (row, row + k) over the tile's samples, one thread each
+    const int row = tid & 63, k = (tid >> 6) + 1;
+    const double *pa = tile + row * kTilePitch, *pb = tile + (row + k) * kTilePitch;
+    double f = INFINITY;
+    for (int q = 0; q < ne; q += 3) {
+      const double dx = pb[q] - pa[q], dy = pb[q + 1] - pa[q + 1], dz = pb[q + 2] - pa[q + 2];
+      f = __builtin_fmin(__builtin_fma(dz, dz, __builtin_fma(dy, dy, dx * dx)), f);
+    }
+    sF[k - 1][row] = r0 + row + k < N ? f : INFINITY;      // (rows past the end replay row N - 1)
+  }
+  __syncthreads();
+  if (tid < kTileRows + kTileHalo) {
+    // row t of the tile (the halo rows too): its pairs with the rows after it and before it
     double b = INFINITY;
 #pragma unroll
-    for (int k = 1; k <= kBoundReach; ++k) {
-      b = __builtin_fmin(b, sF[k - 1][t]);
-      if (t >= k) b = __builtin_fmin(b, sF[k - 1][t - k]);
+    for (int k = 1; k <= kTileHalo; ++k) {
+      if (tid < kTileRows) b = __builtin_fmin(b, sF[k - 1][tid]);
+      if (tid >= k && tid - k < kTileRows) b = __builtin_fmin(b, sF[k - 1][tid - k]);
     }
-    if (!live) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) g8[k] = k < 3 ? INFINITY : -INFINITY;
-    }
-    const bool empty = !(g8[0] <= g8[3]);
-    g8[6] = (!live || empty) ? 0.0 : b;
-    // per aligned group of 8 lanes (8 consecutive threads are 8 consecutive sorted drones)
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      auto fold = [k](double a, double c) { return k < 3 ? fmin(a, c) : fmax(a, c); };
-      g8[k] = fold(g8[k], dpp_f64<0xB1>(g8[k]));      // lane xor 1
-      g8[k] = fold(g8[k], dpp_f64<0x4E>(g8[k]));      // lane xor 2
-      g8[k] = fold(g8[k], dpp_f64<0x141>(g8[k]));     // mirror inside the half-row of 8
-    }
-    const int J = r / kColBlock;
-    if (live && (t & 7) == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) colbox[(size_t)J * 6 + k] = g8[k];
-      cmax[J] = g8[6];
-    }
+    if (b < INFINITY && r0 + tid < N) atomicMin(&bound[r0 + tid], (unsigned long long)__double_as_longlong(b));
   }
 }
 
-bool collide_counts_by_groups(const msnap_ctx *ctx, int shares_surviving, int group_pairs_surviving) {
-  CullGroups cg{};
-  cg.cap = ctx->collide_last_gcap;
-  cg.mode = ctx->collide_last_mode;
-  return cull_use_groups(shares_surviving, group_pairs_surviving, cg);
+// what the cost model makes of a pass's survivor counts (the choice the NEXT pass of this swarm takes from the hint)
+bool collide_counts_by_groups(const msnap_ctx *ctx, int n_drones, int shares_surviving, int group_pairs_surviving) {
+  if (ctx->collide_cull_mode == 1 || n_drones > kCullGroupMaxDrones) return false;
+  if (ctx->collide_cull_mode == 2) return true;
+  return cull_groups_cheaper(shares_surviving, group_pairs_surviving);
 }
 
 // whether a pass with these arguments runs behind the exact broad phase (which builds its own, spatially sorted, row
@@ -1875,7 +2062,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0, ctx->stream,
                        (const double *)nullptr, (const int32_t *)nullptr, g, (const double *)nullptr,
                        (const int32_t *)nullptr, radius, min_dist, partner, hit, (const int32_t *)nullptr,
-                       (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
+                       (const int32_t *)nullptr, (const int32_t *)nullptr);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
@@ -1949,78 +2136,117 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   ctx->collide_last_shares = (int)(waves < 0x7fffffff ? waves : 0x7fffffff);
   const int E = n_samples * 3;
   if (cull) {
-    // Buffers: sorted row image [E][Rp] | sorted columns [N][E] | box [N][6] | colbox [nJ][6] | cmax [nJ] | row-side entries (d2) | column-side slots (d2) || row-side entries (j) |
-    // column-side slots (j, pre-filled -1) | sort keys [N] | perm [N] | survivor list [shares] | cnt [n_rb] | meta [kMetaWords]
+    // Launches: [key, unless the sampler left boxes and keys] -> rank -> gather -> select -> evaluator -> fold, the last
+    // two either
+    //   * the surviving GROUP PAIRS (8 x 8 drones) and the per-group fold of their candidates, or
+    //   * the surviving SHARES (128 x 8) and the merge of their entries.
+    // Which one is a HOST decision (the launch sequences differ): "collide_cull_mode" 1 / 2 force it; otherwise the
+    // survivor counts the previous pass of this context left in page-locked memory (cull_hint_pack; read without
+    // synchronising, so possibly a few passes old) are put through the cost model, and a pass without such a hint
+    // for its swarm size takes the shares.  Both evaluators are exact; the choice only moves time.
     const int N = n_rows;
     const size_t nJ = ((size_t)N + kColBlock - 1) / kColBlock;
     long long shares = 0;
     for (int I = 0; I < g.n_rb; ++I) shares += (N - I * kRowBlock + kColBlock - 1) / kColBlock;
+    const long long all_groups = (long long)nJ * (nJ + 1) / 2;
+    const bool groups_fit = N <= kCullGroupMaxDrones;
+    bool by_groups = false;
+    if (ctx->collide_cull_mode == 2) {
+      by_groups = groups_fit;
+    } else if (ctx->collide_cull_mode != 1 && groups_fit && ctx->cull_hint) {
+      const unsigned long long h = *(volatile unsigned long long *)ctx->cull_hint;
+      const int hN = (int)(h >> 48) & 0x7fff;
+      const long long hs = (long long)((h >> 24) & 0xffffff), hg = (long long)(h & 0xffffff);
+      by_groups = h != 0 && hN == N && hg != 0xffffff && cull_groups_cheaper(hs, hg);
+    }
     // sample parts a share may be cut into: the column-side slots are n_rb x spmax x N entries, pre-filled per call
     const int spmax = N > 8192 ? 2 : kCullMaxParts;
     ctx->collide_last_shares = (int)shares;
     const int sp_force = (ctx->collide_sample_parts > 0 ? (ctx->collide_sample_parts < spmax ? ctx->collide_sample_parts : spmax) : 0) |
                          (spmax << 8);
-    // row-side entries: one per item; cull_split cuts shares only while the items stay below twice the wave slots
+    // share evaluator: row-side entries, one per item (cull_split cuts shares only while the items stay below twice the
+    // wave slots), column-side slots.  Group evaluator: list, 16 candidate slots per item, reverse lists
     const long long items_max = (sp_force & 0xff) ? shares * (sp_force & 0xff) : (shares > 2 * slots ? shares : 2 * slots);
-    const size_t entries = (size_t)items_max * kRowBlock;
-    const size_t centries = (size_t)g.n_rb * spmax * N;
-    // group-pair path (CullGroups): list, candidate slots (16 per item), per-drone atomics
-    const long long all_groups = (long long)nJ * (nJ + 1) / 2;
-    const int gcap = (int)(all_groups < kGroupCap ? all_groups : kGroupCap);
-    const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 7 + entries + centries +
-                           (size_t)gcap * 16 /* cand_d2 */ + (size_t)N /* dmin */;
-    const size_t ints = entries + centries + (size_t)N /* sort keys */ + (size_t)N + (size_t)shares + g.n_rb + kMetaWords +
-                        (size_t)gcap /* glist */ + (size_t)gcap * 16 /* cand_j */ + (size_t)N /* pmin */;
+    const size_t entries = by_groups ? 0 : (size_t)items_max * kRowBlock;
+    const size_t centries = by_groups ? 0 : (size_t)g.n_rb * spmax * N;
+    const size_t gcap = by_groups ? (size_t)all_groups : 0;
+    // the sampler's hand-over (msnap_sample_collide_device: boxes [N][6], then keys [N]) saves the key launch
+    const bool have_keys = handover_form(ctx, rows_t_in, N, n_samples) == 2;
+    // Buffers (doubles, then ints): sorted row image [E][Rp] | sorted columns [N][E] | box [N][6] | colbox [nJ][6] |
+    // bound [N] | row-side entries | column-side slots | candidates [gcap][16] || entries (j) | slots (j, pre-filled -1) |
+    // keys [N] | perm [N] | survivor list [shares] | cnt [n_rb] | meta | acnt, astart [nJ] | blist [nJ][nJ] (zeroed per
+    // pass) | glist [gcap] | cand_j [gcap][16]
+    const size_t doubles = (size_t)g.Rp * E + (size_t)N * E + (size_t)N * 6 + nJ * 6 + (size_t)N + entries + centries + gcap * 16;
+    const size_t ints = entries + centries + (size_t)N + (size_t)N + (size_t)shares + g.n_rb + kMetaWords + 2 * nJ + gcap +
+                        gcap * 16 + (by_groups ? nJ * nJ : 0);
     int rc = ensure(ctx, ctx->stage[7], doubles * sizeof(double) + ints * sizeof(int32_t) + 64);
     if (rc) return rc;
     double *rows_t = (double *)ctx->stage[7].p;
-    double *psorted = rows_t + (size_t)g.Rp * E, *box = psorted + (size_t)N * E, *colbox = box + (size_t)N * 6;
-    double *cmax = colbox + nJ * 6;
-    double *pd = cmax + nJ, *cd = pd + entries;
+    double *psorted = rows_t + (size_t)g.Rp * E, *box_own = psorted + (size_t)N * E, *colbox = box_own + (size_t)N * 6;
+    unsigned long long *bound = (unsigned long long *)(colbox + nJ * 6);
+    double *pd = (double *)(bound + N), *cd = pd + entries;
     double *cand_d2 = cd + centries;
-    unsigned long long *dmin = (unsigned long long *)(cand_d2 + (size_t)gcap * 16);
-    int32_t *pj = (int32_t *)(dmin + N), *ci = pj + entries;
-    unsigned *key = (unsigned *)(ci + centries);
-    int32_t *perm = (int32_t *)(key + N), *surv = perm + N, *cnt = surv + shares, *meta = cnt + g.n_rb;
-    int32_t *glist = meta + kMetaWords, *cand_j = glist + gcap, *pmin = cand_j + (size_t)gcap * 16;
-    CullGroups cg{glist, dmin, pmin, cand_d2, cand_j, gcap, ctx->collide_cull_mode};
+    int32_t *pj = (int32_t *)(cand_d2 + gcap * 16), *ci = pj + entries;
+    unsigned *key_own = (unsigned *)(ci + centries);
+    int32_t *perm = (int32_t *)(key_own + N), *surv = perm + N, *cnt = surv + shares, *meta = cnt + g.n_rb;
+    int32_t *acnt = meta + kMetaWords, *astart = acnt + nJ;
+    int32_t *blist = astart + nJ, *glist = blist + (by_groups ? nJ * nJ : 0), *cand_j = glist + gcap;
+    const double *box = have_keys ? rows_t_in : box_own;
+    const unsigned *key = have_keys ? reinterpret_cast<const unsigned *>(rows_t_in + (size_t)N * 6) : key_own;
+    CullGroups cg{glist, astart, acnt, blist, cand_d2, cand_j, (int)gcap, (int)nJ};
+    // the reverse lists are all-zero between passes (the fold zeroes what it read): they are cleared only when this
+    // block has held something else since -- another layout, another evaluator, any other pass of the context -- and,
+    // so that a graph replays whatever ran between its replays, always under stream capture
+    // (nor is a block trusted that a graph may replay on between two eager passes)
+    const bool trust = by_groups && !stream_is_capturing(ctx) && !ctx->stage[7].in_graph;
+    const bool blist_clean = trust && ctx->blist_clean == (const void *)blist && ctx->blist_clean_n == (int)nJ;
+    ctx->blist_clean = trust ? (const void *)blist : nullptr;
+    ctx->blist_clean_n = (int)nJ;
     ctx->collide_meta = meta;
     ctx->collide_last_cull = 1;
-    ctx->collide_last_gcap = gcap;
-    ctx->collide_last_mode = ctx->collide_cull_mode;
-    hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
-                       ctx->stream, pos_cols, N, n_samples, box, key, meta);
-    MSNAP_HIP(ctx, hipGetLastError());
+    ctx->collide_last_by_groups = by_groups ? 1 : 0;
+    ctx->collide_last_n = N;
+    if (!have_keys) {
+      hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
+                         ctx->stream, pos_cols, N, n_samples, box_own, key_own);
+      MSNAP_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL((N <= 4096 ? collide_rank_kernel<4> : N <= 8192 ? collide_rank_kernel<8> : collide_rank_kernel<16>),
-                       dim3((N + kRankTile - 1) / kRankTile), dim3(kWave * kRankWaves), 0, ctx->stream,
-                       (const unsigned *)key, N, perm);
+                       dim3((N + kRankTile - 1) / kRankTile), dim3(kWave * kRankWaves), 0, ctx->stream, key, N, perm, box,
+                       bound, blist, (int)(by_groups && !blist_clean ? nJ * nJ : 0), meta);
     MSNAP_HIP(ctx, hipGetLastError());
-    const int ny = (E + 31) / 32;
-    hipLaunchKernelGGL(collide_transpose_kernel, dim3(g.Rp / 64, ny + 4), dim3(256), 0, ctx->stream, pos_cols, N, g.Rp, E,
-                       rows_t, ny, ci, centries, (const int32_t *)perm, psorted);
+    const int nx = g.Rp / kTileRows, ny = (E + kTileE - 1) / kTileE;
+    const int n_box = (int)((nJ + kBoxGroups - 1) / kBoxGroups), n_fill = by_groups ? 0 : 4 * nx;
+    hipLaunchKernelGGL(collide_gather_kernel, dim3((unsigned)(nx * ny + n_box + n_fill)), dim3(256), 0, ctx->stream, pos_cols, N,
+                       g.Rp, E, rows_t, psorted, (const int32_t *)perm, bound, box, colbox, nx, ny, n_box, ci, centries);
     MSNAP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(collide_bound_kernel, dim3((N + kBoundRows - 1) / kBoundRows), dim3(kBoundRows * kBoundGroups), 0,
-                       ctx->stream, (const double *)rows_t, g.Rp, N, n_samples, (const double *)box, (const int32_t *)perm,
-                       colbox, cmax, dmin, pmin);
-    MSNAP_HIP(ctx, hipGetLastError());
-    CollideCull cu{colbox, cmax};
-    hipLaunchKernelGGL((N <= 8192 ? collide_select_kernel<4> : collide_select_kernel<8>),
+    CollideCull cu{colbox};
+    hipLaunchKernelGGL((N <= kCullGroupMaxDrones ? collide_select_kernel<1> : collide_select_kernel<2>),
                        dim3(g.n_rb + (unsigned)((nJ + kSelGroups - 1) / kSelGroups)), dim3(kSelThreads), 0, ctx->stream, N, g.n_rb, cu,
-                       surv, cnt, meta, cg);
+                       (const double *)bound, surv, cnt, meta, cg);
     MSNAP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(collide_eval_kernel, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
+    if (by_groups) {
+      hipLaunchKernelGGL(collide_eval_groups_kernel, dim3((unsigned)(ctx->n_cu * 4 * kGroupWaves)), dim3(kWave), 0, ctx->stream,
+                         (const double *)psorted, N, n_samples, (const int32_t *)perm, (const int32_t *)meta, cg, ctx->cull_hint);
+      MSNAP_HIP(ctx, hipGetLastError());
+      hipLaunchKernelGGL(collide_finish_groups_kernel, dim3((unsigned)((nJ + kFinishWaves - 1) / kFinishWaves)),
+                         dim3(kWave * kFinishWaves), 0, ctx->stream, N, (const int32_t *)perm, cg, radius, min_dist, partner, hit);
+      MSNAP_HIP(ctx, hipGetLastError());
+      return MSNAP_OK;
+    }
+    hipLaunchKernelGGL(collide_eval_shares_kernel, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
                        (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, sp_force,
-                       (int)slots, meta, cg);
-    MSNAP_HIP(ctx, hipGetLastError());
-    hipLaunchKernelGGL(collide_resolve_kernel, dim3((unsigned)(ctx->n_cu * 4)), dim3(256), 0, ctx->stream, N,
-                       (const int32_t *)meta, cg);
+                       (int)slots, meta, ctx->cull_hint);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                        ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)perm,
-                       (const int32_t *)cnt, (const int32_t *)meta, cg);
+                       (const int32_t *)cnt, (const int32_t *)meta);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }
+  // (a row image is only what the sampler's record says it is: a hand-over in the keys form -- written for a whole-
+  // swarm pass that, by the options now in force, is not taken --, for other rows, or not on record is not one)
+  if (handover_form(ctx, rows_t_in, n_rows, n_samples) != 1) rows_t_in = nullptr;
   if (ctx->collide_sample_parts > 0) {
     g.sparts = ctx->collide_sample_parts < 8 ? ctx->collide_sample_parts : 8;
   } else if (ctx->collide_waves_per_cu == 0) {
@@ -2031,6 +2257,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   const size_t part_entries = ((size_t)waves + g.n_rb) * g.sparts * kRowBlock;
   const size_t centries = g.sym ? cpart_entries * g.sparts : 0;
   const size_t t_entries = rows_t_in ? 0 : (size_t)g.Rp * E;
+  ctx->blist_clean = nullptr;      // (the block is about to hold this pass's buffers)
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
@@ -2050,7 +2277,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
   MSNAP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(collide_merge_kernel, dim3((n_rows + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)nullptr,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
+                     (const int32_t *)nullptr, (const int32_t *)nullptr);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
@@ -2140,6 +2367,7 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   if ((part_entries + centries) * 12 > ((size_t)16 << 30)) return MSNAP_ENOMEM;
   ctx->collide_last_cull = 0;      // (the buffer the last broad-phase pass left its counts in is reused)
   ctx->collide_meta = nullptr;
+  ctx->blist_clean = nullptr;      // (the block is about to hold this pass's buffers)
   int rc = ensure(ctx, ctx->stage[7],
                   t_entries * sizeof(double) + (part_entries + centries) * (sizeof(double) + sizeof(int32_t)) + 64);
   if (rc) return rc;
@@ -2164,7 +2392,7 @@ int launch_formation_collide_part(msnap_ctx *ctx, int N, int n_samples, const do
   }
   hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                      ctx->stream, pd, pj, g, cd, ci, 0.0, out_d2, out_j, (int32_t *)nullptr, (const int32_t *)nullptr,
-                     (const int32_t *)nullptr, (const int32_t *)nullptr, CullGroups{});
+                     (const int32_t *)nullptr, (const int32_t *)nullptr);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }

@@ -97,8 +97,22 @@ struct msnap_ctx {
   int collide_cull_min_drones = 0;   // "collide_cull_min_drones": smallest whole swarm that takes the broad phase (0: default 3072)
   int collide_last_cull = 0;    // "collide_last_cull" (read): 1 if the last msnap_formation_collide took the broad-phase path
   int collide_last_shares = 0;  // "collide_last_shares" (read): 8-column x 128-row shares of that pass before the broad phase
-  const int32_t *collide_meta = nullptr;   // device: its survivor count at [64] ("collide_last_survivors", read: synchronises)
-  int collide_last_gcap = 0, collide_last_mode = 0;   // of that pass: its group-pair list capacity and "collide_cull_mode"
+  const int32_t *collide_meta = nullptr;   // device: its survivor counts ("collide_last_survivors" / "_group_pairs", read: synchronise)
+  int collide_last_by_groups = 0;   // "collide_last_by_groups" (read): that pass's evaluator walked the surviving group pairs
+  int collide_last_n = 0;           // its swarm size
+  const void *blist_clean = nullptr;   // the group evaluator's reverse lists at this address (for blist_clean_n groups) are all-zero
+  int blist_clean_n = 0;
+  // one 64-bit word in page-locked host memory the broad phase's evaluator writes its survivor counts to: the next
+  // pass's choice of evaluator reads it without synchronising (csrc/msnap_aux.hip::cull_hint_pack)
+  unsigned long long *cull_hint = nullptr;
+  // what msnap_sample_collide_device left for the pairwise pass, and where (the last few buffers it wrote): 1 the
+  // transposed row image, 2 the per-drone boxes and sort keys of a whole-swarm pass behind the broad phase.  A buffer
+  // the pass is handed that is not on record -- or whose record does not fit the pass -- is ignored, never misread.
+  struct Handover {
+    const void *ptr = nullptr;
+    int n = 0, s = 0, form = 0;
+  } handover[8];
+  int handover_next = 0;
   int collide_last_sym = 0;     // "collide_last_sym" (read): 1 if the last msnap_formation_collide evaluated its own-range pairs once
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
   msnap::RetiredBuf *retired = nullptr;   // blocks kept alive for graphs captured before they were outgrown
@@ -111,8 +125,10 @@ namespace msnap {
 int record_hip_error(msnap_ctx *ctx, hipError_t e, const char *what);
 int ensure(msnap_ctx *ctx, DevBuf &b, size_t bytes);
 bool stream_is_capturing(const msnap_ctx *ctx);
+// form (1 row image, 2 boxes and keys; 0: not on record for n drones x n_samples) of a sampler hand-over buffer
+int handover_form(const msnap_ctx *ctx, const void *ptr, int n, int n_samples);
 // what the last broad-phase pass evaluated (device-side choice of collide_eval_kernel, restated on its counts)
-bool collide_counts_by_groups(const msnap_ctx *ctx, int shares_surviving, int group_pairs_surviving);
+bool collide_counts_by_groups(const msnap_ctx *ctx, int n_drones, int shares_surviving, int group_pairs_surviving);
 
 // records the kernel instance a solve launcher chose (msnap_last_kernel; bench.py labels its rooflines with it)
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -131,7 +147,7 @@ int launch_pack(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, con
 int launch_formation_transform(msnap_ctx *ctx, int n_poses, int n_offsets, const double *rb_pose,
                                const double *offsets, double *out);
 int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
-                  double dt, int n_samples, int n_axes, double *pos, double *pos_t);
+                  double dt, int n_samples, int n_axes, double *pos, double *pos_t, bool keys_form);
 int launch_eval_flat(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
                      int n_samples, const double *ts, double *out);
 int launch_snap_cost(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double *cost);

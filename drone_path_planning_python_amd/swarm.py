@@ -102,11 +102,11 @@ class DeviceCompute:
         return pos
 
     def sample_rows_t(self, coef, dur, dt, n_samples, n_cols=None):
-        """(pos [n, S, 3], pos_t): the sampler's second output is the transposed row image [S][3][pitch] the
-        pairwise pass reads -- `collide(..., rows_t=pos_t)` then skips its own transposition pass.  With `n_cols`
-        (the columns these rows, as a shard at offset 0, will meet) the library is asked first whether that pass would
-        read the image at all -- a whole swarm behind the exact broad phase sorts itself spatially and builds its own --
-        and pos_t is None if not."""
+        """(pos [n, S, 3], pos_t): the sampler's second output is what the pairwise pass over these drones would
+        otherwise compute in a launch of its own -- the transposed row image [S][3][pitch], or (a whole swarm behind the
+        exact broad phase) the drones' path boxes and sort keys; `collide(..., rows_t=pos_t)` hands it over.  With
+        `n_cols` (the columns these rows, as a shard at offset 0, will meet) the library is asked first whether that
+        pass reads a hand-over at all (paths shorter than 6 samples do not), and pos_t is None if not."""
         torch = self.torch
         n, M = dur.shape
         if n_cols is not None and not self.ctx.collide_reads_rows_t(n, 0, n_cols, n_samples):

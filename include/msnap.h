@@ -124,9 +124,12 @@ int msnap_host_free(void *ptr);
  *                          (the shares that pass it) and "collide_last_group_pairs" (the 8 x 8 group pairs that
  *                          pass it; both synchronise the stream).  msnap_set_option refuses the read-only names
  *                          ("collide_last_*") with MSNAP_EINVAL
- *   "collide_cull_mode"    what the broad phase evaluates: 0 (default) chosen per pass on the device -- the surviving
- *                          8 x 8 group pairs when they are few against the surviving 128 x 8 shares --, 1 always
- *                          the shares, 2 always the group pairs (while their list holds them: 262144)
+ *   "collide_cull_mode"    what the broad phase evaluates: 1 the surviving 128 x 8 shares (then a merge launch), 2 the
+ *                          surviving 8 x 8 group pairs, finished inside the evaluator's launch (swarms up to 8192
+ *                          drones: every group pair has a list slot), 0 (default) chosen per pass on the HOST -- the
+ *                          two launch sequences differ -- from the survivor counts the context's previous pass over a
+ *                          swarm of this size left in page-locked memory (read without synchronising; a pass without
+ *                          such counts takes the shares).  Results are identical either way
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
@@ -271,16 +274,19 @@ int msnap_formation_collide_device(msnap_ctx *ctx, int n_rows, int row_offset, i
                                    const double *pos_cols, double radius,
                                    double *min_dist, int32_t *partner, int32_t *hit);
 
-/* The same pass for a caller that already holds the rows' TRANSPOSED image -- what msnap_sample_collide_device
- * writes next to the positions: pos_rows_t [n_samples][3][P], P = n_rows rounded up to whole 128-row blocks
- * (msnap_collide_rows_t_doubles(n_rows, n_samples) doubles in all; the rows behind n_rows are never credited).
- * The pass reads its rows from that image (512 contiguous bytes per wave and load); given it, it skips its own
- * transposition pass over pos_rows.  Device pointers only: the pair exists to keep the formation pipeline
- * (sampler -> pairwise pass) on the GPU without the intermediate pass. */
+/* The same pass for a caller whose positions come from this library's sampler: msnap_sample_collide_device writes,
+ * next to the positions, what the pass over these drones would otherwise compute in a launch of its own -- into
+ * pos_rows_t, msnap_collide_rows_t_doubles(n_rows, n_samples) doubles, whose content is the pair's private matter:
+ *   - the rows' TRANSPOSED image [n_samples][3][P], P = n_rows rounded up to whole 128-row blocks (the pass reads its
+ *     rows from it, 512 contiguous bytes per wave and load, and skips its own transposition pass), or
+ *   - where the pass over the n_rows drones as a whole swarm runs behind the exact broad phase: every drone's path
+ *     box and sort key (the sampler has the samples in LDS; the pass then starts with its sort, without a key launch).
+ * The context remembers which of the two it last wrote and where; a buffer that is not that hand-over (or no longer
+ * fits the options in force) is ignored, never misread.  Device pointers only: the pair exists to keep the formation
+ * pipeline (sampler -> pairwise pass) on the GPU without the intermediate launch. */
 size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples);
-/* 1 if msnap_formation_collide_t_device with these arguments would read the row image, 0 if not -- a whole swarm
- * behind the exact broad phase ("collide_no_cull") is sorted spatially first and builds its own, and paths shorter
- * than 6 samples take plain loops: the caller can then sample with msnap_sample and save the second output. */
+/* 1 if msnap_formation_collide_t_device with these arguments reads the sampler's hand-over, 0 if not (paths shorter
+ * than 6 samples take plain loops: the caller can then sample with msnap_sample and save the second output). */
 int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples);
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
                                 const double *dur, double dt, int n_samples, double *pos, double *pos_t);

@@ -13,14 +13,14 @@ static int unreachable() { abort(); }
 int launch_solve(msnap_ctx *, int, int, const double *, const double *, int, double *, double *, int32_t *) { return unreachable(); }
 int launch_pack(msnap_ctx *, int, int, const double *, const double *, float *) { return unreachable(); }
 int launch_formation_transform(msnap_ctx *, int, int, const double *, const double *, double *) { return unreachable(); }
-int launch_sample(msnap_ctx *, int, int, const double *, const double *, double, int, int, double *, double *) { return unreachable(); }
+int launch_sample(msnap_ctx *, int, int, const double *, const double *, double, int, int, double *, double *, bool) { return unreachable(); }
 int launch_eval_flat(msnap_ctx *, int, int, const double *, const double *, int, const double *, double *) { return unreachable(); }
 int launch_snap_cost(msnap_ctx *, int, int, const double *, const double *, double *) { return unreachable(); }
 int launch_formation_collide(msnap_ctx *, int, int, int, int, const double *, const double *, double, double *, int32_t *,
                              int32_t *, const double *) { return unreachable(); }
 int launch_formation_collide_part(msnap_ctx *, int, int, const double *, int, int, double *, int32_t *) { return unreachable(); }
 bool formation_collide_takes_broad_phase(const msnap_ctx *, int, int, int, int) { return false; }
-bool collide_counts_by_groups(const msnap_ctx *, int, int) { return false; }
+bool collide_counts_by_groups(const msnap_ctx *, int, int, int) { return false; }
 int launch_formation_collide_finish(msnap_ctx *, int, int, const void *, size_t, int, int, double, double *, int32_t *,
                                     int32_t *) { return unreachable(); }
 int launch_mesh_sweep(msnap_ctx *, int, int, const double *, int, const double *, double, double *, int32_t *) { return unreachable(); }

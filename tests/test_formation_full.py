@@ -282,6 +282,43 @@ def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
 
 
 @pytest.mark.gpu
+def test_evaluator_choice_follows_the_previous_pass():
+    """"collide_cull_mode" 0: which evaluator runs behind the broad phase is a host decision (the launch sequences
+    differ: the group pairs finish inside their evaluator, the shares are followed by a merge), taken from the survivor
+    counts the context's previous pass over a swarm of this size left in page-locked memory.  A first pass takes the
+    shares; a sparse swarm then moves to the group pairs, a dense one back to the shares -- results equal throughout."""
+    from drone_path_planning_python_amd import Context
+    rng = np.random.default_rng(21)
+    n, S = 3072, 13
+    sparse, dense = _broad_phase_swarm("sparse", n, S, rng), _broad_phase_swarm("dense", n, S, rng)
+    other = _broad_phase_swarm("sparse", n + 64, S, rng)
+    ref_s, ref_d = c_oracle.formation_collide(sparse, 0.3), c_oracle.formation_collide(dense, 0.3)
+    ref_o = c_oracle.formation_collide(other, 0.3)
+
+    def run(ctx, pos, ref):
+        got = ctx.formation_collide(pos, pos, 0.3)           # (host entry: synchronises, the hint is in place)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        assert ctx.get_option("collide_last_cull") == 1
+        return ctx.get_option("collide_last_by_groups")
+
+    with Context(order=7, max_segments=16) as ctx:
+        assert run(ctx, sparse, ref_s) == 0                  # no counts yet: the shares
+        assert run(ctx, sparse, ref_s) == 1                  # few group pairs survive: the group evaluator
+        assert run(ctx, sparse, ref_s) == 1
+        assert run(ctx, other, ref_o) == 0                   # another swarm size: the counts do not apply
+        assert run(ctx, dense, ref_d) == 0                   # ... and now they are that swarm's
+        assert run(ctx, sparse, ref_s) == 0                  # stale for this size too by now
+        assert run(ctx, sparse, ref_s) == 1
+        assert run(ctx, dense, ref_d) == 1                   # a swarm that turned dense pays once ...
+        assert run(ctx, dense, ref_d) == 0                   # ... and goes back to the shares
+        ctx.set_option("collide_cull_mode", 2)
+        assert run(ctx, dense, ref_d) == 1
+        ctx.set_option("collide_cull_mode", 1)
+        assert run(ctx, sparse, ref_s) == 0
+
+
+@pytest.mark.gpu
 def test_broad_phase_is_the_default_for_a_whole_large_swarm_only(ctx7):
     rng = np.random.default_rng(5)
     pos = _broad_phase_swarm("sparse", 3072, 7, rng)
@@ -297,26 +334,35 @@ def test_broad_phase_is_the_default_for_a_whole_large_swarm_only(ctx7):
 def test_row_image_query_follows_the_broad_phase(ctx7):
     """msnap_formation_collide_reads_rows_t: a caller that has the sampler write the pairwise pass's row image asks
     first -- a whole swarm behind the broad phase builds its own."""
-    assert ctx7.collide_reads_rows_t(1024, 0, 1024, 91)            # small swarm: the plain pass reads it
-    assert not ctx7.collide_reads_rows_t(4096, 0, 4096, 91)        # whole large swarm: sorted first
+    assert ctx7.collide_reads_rows_t(1024, 0, 1024, 91)            # small swarm: the plain pass reads the row image
+    assert ctx7.collide_reads_rows_t(4096, 0, 4096, 91)            # whole large swarm: the sampler's boxes and sort keys
     assert ctx7.collide_reads_rows_t(2048, 0, 4096, 91)            # a shard
     assert ctx7.collide_reads_rows_t(2048, 2048, 4096, 91)
     assert not ctx7.collide_reads_rows_t(4096, 0, 4096, 3)         # shorter than a sample chunk: plain loops
-    ctx7.set_option("collide_no_cull", 1)
-    try:
-        assert ctx7.collide_reads_rows_t(4096, 0, 4096, 91)
-    finally:
-        ctx7.set_option("collide_no_cull", 0)
     from drone_path_planning_python_amd import swarm as sw
     import torch
     comp = sw.DeviceCompute(ctx7, torch)
     try:
         wp, t = synthetic.swarm(41, 3072, 4)
         coef, dur, status = comp.solve(torch.from_numpy(wp).cuda(), torch.from_numpy(t).cuda())
-        pos, rows_t = comp.sample_rows_t(coef, dur, 0.1, 12, n_cols=3072)
-        assert rows_t is None
+        pos, keys = comp.sample_rows_t(coef, dur, 0.1, 12, n_cols=3072)
         pos2, rows_t2 = comp.sample_rows_t(coef[:1000], dur[:1000], 0.1, 12, n_cols=1000)
-        assert rows_t2 is not None and torch.equal(pos[:1000], pos2)
+        assert keys is not None and rows_t2 is not None and torch.equal(pos[:1000], pos2)
+        pos3, none = comp.sample_rows_t(coef, dur, 0.1, 4, n_cols=3072)
+        assert none is None
+        # the hand-over of the whole swarm (boxes and sort keys) and its pass; then the same buffer offered to passes it
+        # was not written for -- the broad phase switched off, another swarm size: ignored, never misread
+        ref = c_oracle.formation_collide(pos.cpu().numpy(), 0.3)
+        for no_cull, rows in ((0, 3072), (1, 3072), (0, 3000)):
+            ctx7.set_option("collide_no_cull", no_cull)
+            try:
+                got = comp.collide(pos[:rows], 0, pos[:rows], 0.3, rows_t=keys)
+                assert ctx7.get_option("collide_last_cull") == (0 if no_cull or rows < 3072 else 1)
+            finally:
+                ctx7.set_option("collide_no_cull", 0)
+            want = ref if rows == 3072 else c_oracle.formation_collide(pos[:rows].cpu().numpy(), 0.3)
+            np.testing.assert_array_equal(got[0].cpu().numpy(), want[0])
+            np.testing.assert_array_equal(got[1].cpu().numpy(), want[1])
     finally:
         comp.close()
 
@@ -441,10 +487,12 @@ def test_read_only_options_and_last_pass_reports(ctx7):
     surv, groups = ctx7.get_option("collide_last_survivors"), ctx7.get_option("collide_last_group_pairs")
     by_groups, pairs = ctx7.get_option("collide_last_by_groups"), ctx7.get_option("collide_last_pairs_evaluated")
     assert ctx7.get_option("collide_last_cull") == 1 and 0 < surv <= ctx7.get_option("collide_last_shares")
-    assert pairs == (groups * 64 if by_groups else surv * 1024) and pairs < n * (n - 1) // 2 // 8
+    assert pairs == (groups * 64 if by_groups else surv * 1024) and pairs < n * (n - 1) // 2 // 2 and groups * 64 < pairs
     assert ctx7.whole_pass_pays(n, 4) and ctx7.whole_pass_pays(n, 8)
     dense = _broad_phase_swarm("dense", n, S, rng)
-    ctx7.formation_collide(dense, dense, 0.3)
+    ctx7.formation_collide(dense, dense, 0.3)          # (by whichever evaluator the sparse pass's counts chose)
+    assert ctx7.get_option("collide_last_pairs_evaluated") >= n * (n - 1) // 2
+    ctx7.formation_collide(dense, dense, 0.3)          # nothing was culled: back to the shares
     assert ctx7.get_option("collide_last_by_groups") == 0
     assert ctx7.get_option("collide_last_pairs_evaluated") >= n * (n - 1) // 2
     assert not ctx7.whole_pass_pays(n, 2)
