@@ -1493,7 +1493,9 @@ collide_eval_groups_kernel(const double *__restrict__ pcol, int N, int S, const 
   // (the first list entry is fetched beside the survivor count, the next one under the current item)
   int entry = (int)blockIdx.x < cg.cap ? cg.glist[blockIdx.x] : 0;
   for (int it = blockIdx.x; it < tot; it += gridDim.x) {
-    const int a = entry >> 16, b = entry & 0xffff;
+    // (the entry is wave-uniform: as a scalar the drones' row bases are scalar too, and every load is base + one lane offset)
+    const int ent = __builtin_amdgcn_readfirstlane(entry);
+    const int a = ent >> 16, b = ent & 0xffff;
     const bool diag = a == b;
     entry = it + (int)gridDim.x < tot ? cg.glist[it + gridDim.x] : 0;
 
@@ -1508,21 +1510,37 @@ collide_eval_groups_kernel(const double *__restrict__ pcol, int N, int S, const 
 #pragma unroll 1
     for (int s0 = 0; s0 < S; s0 += kGroupLanes) {
       const int sq = s0 + ls < S ? s0 + ls : S - 1;      // (a sample seen twice does not change a minimum)
-      const unsigned off = (unsigned)sq * 3u;
+      // one 32-bit lane offset for all loads of the trip: scalar drone base + zero-extended lane offset + immediate
+      const unsigned voff = (unsigned)sq * 24u;
       double cx[kGroupHalf], cy[kGroupHalf], cz[kGroupHalf];
 #pragma unroll
       for (int c = 0; c < kGroupHalf; ++c) {
         const int d = b * kColBlock + half * kGroupHalf + c;      // (a last group may be short: clamped, masked below)
-        const double *p = pcol + (size_t)(d < N ? d : N - 1) * stride;
-        cx[c] = p[off];
-        cy[c] = p[off + 1];
-        cz[c] = p[off + 2];
+        const double *p = reinterpret_cast<const double *>(
+            reinterpret_cast<const char *>(pcol + (size_t)(d < N ? d : N - 1) * stride) + (size_t)voff);
+        cx[c] = p[0];
+        cy[c] = p[1];
+        cz[c] = p[2];
       }
+      // The row drones' samples are fetched two rows ahead of the arithmetic, through a ring of three register sets.
+      // Left to the compiler every row was load, wait, 28 operations -- 24 dependent L2 round trips per item, the whole
+      // of the kernel's 21 us; the compiler barrier pins each fetch in front of the arithmetic two rows earlier.
+      double rw[3][3];
+      auto fetch = [&](int r, double(&dst)[3]) {
+        const int d = a * kColBlock + r;
+        const double *p = reinterpret_cast<const double *>(
+            reinterpret_cast<const char *>(pcol + (size_t)(d < N ? d : N - 1) * stride) + (size_t)voff);
+        dst[0] = p[0];
+        dst[1] = p[1];
+        dst[2] = p[2];
+      };
+      fetch(0, rw[0]);
+      fetch(1, rw[1]);
 #pragma unroll
       for (int r = 0; r < kColBlock; ++r) {
-        const int d = a * kColBlock + r;
-        const double *p = pcol + (size_t)(d < N ? d : N - 1) * stride;
-        const double x = p[off], y = p[off + 1], z = p[off + 2];
+        if (r + 2 < kColBlock) fetch(r + 2, rw[(r + 2) % 3]);
+        asm volatile("" ::: "memory");
+        const double x = rw[r % 3][0], y = rw[r % 3][1], z = rw[r % 3][2];
 #pragma unroll
         for (int c = 0; c < kGroupHalf; ++c) {
           const double dx = cx[c] - x, dy = cy[c] - y, dz = cz[c] - z;
