@@ -124,12 +124,13 @@ int msnap_host_free(void *ptr);
  *                          (the shares that pass it) and "collide_last_group_pairs" (the 8 x 8 group pairs that
  *                          pass it; both synchronise the stream).  msnap_set_option refuses the read-only names
  *                          ("collide_last_*") with MSNAP_EINVAL
- *   "collide_cull_mode"    what the broad phase evaluates: 1 the surviving 128 x 8 shares (then a merge launch), 2 the
- *                          surviving 8 x 8 group pairs, finished inside the evaluator's launch (swarms up to 8192
- *                          drones: every group pair has a list slot), 0 (default) chosen per pass on the HOST -- the
- *                          two launch sequences differ -- from the survivor counts the context's previous pass over a
- *                          swarm of this size left in page-locked memory (read without synchronising; a pass without
- *                          such counts takes the shares).  Results are identical either way
+ *   "collide_cull_mode"    what the broad phase evaluates: 1 the surviving 128 x 8 shares (then the merge of their
+ *                          entries), 2 the surviving 8 x 8 group pairs (then the per-group fold of their candidates;
+ *                          swarms up to 8192 drones: every group pair has a list slot), 0 (default) chosen per pass
+ *                          on the HOST -- the two launch sequences and their buffers differ -- from the survivor
+ *                          counts the context's previous pass over a swarm of this size left in page-locked memory
+ *                          (read without synchronising; a pass without such counts takes the shares).  Results are
+ *                          identical either way
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
