@@ -307,7 +307,8 @@ int msnap_get_option(const msnap_ctx *ctx, const char *name, long *value) {
           hipMemcpy(&groups, ctx->collide_meta + MSNAP_COLLIDE_META_GROUPS, sizeof groups, hipMemcpyDeviceToHost) != hipSuccess)
         return MSNAP_EHIP;
     }
-    const bool by_groups = culled && ctx->collide_last_by_groups;
+    // (a large swarm's group evaluator ran only if its survivors fit the list: 1 << 18 slots, csrc/msnap_aux.hip)
+    const bool by_groups = culled && (ctx->collide_last_by_groups == 1 || (ctx->collide_last_by_groups == 2 && groups <= (1 << 18)));
     if (!strcmp(name, "collide_last_group_pairs")) *value = groups;
     else if (!strcmp(name, "collide_last_survivors")) *value = shares;
     else if (!strcmp(name, "collide_last_by_groups")) *value = by_groups ? 1 : 0;

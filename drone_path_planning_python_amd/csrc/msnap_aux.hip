@@ -1044,6 +1044,8 @@ constexpr int kCullMaxParts = 8;
 constexpr int kCullMaxDrones = 16384;      // largest whole swarm that takes the broad phase (the rank count's words per lane)
 constexpr int kCullMinDrones = 3072;       // smallest, by default ("collide_cull_min_drones")
 constexpr int kCullGroupMaxDrones = 8192;  // largest whose group pairs are all given a list slot (524 800): the group evaluator
+constexpr int kGroupCapLarge = 1 << 18;    // list slots of larger swarms (16 384 drones have 2.1 M group pairs): the group
+                                           // evaluator runs while the survivors fit, the share evaluator behind it otherwise
 struct CullSplit {
   int lo, hi, x;      // x shares in `hi` parts, the others in `lo`
   __device__ __host__ __forceinline__ int items(int tot) const { return x * hi + (tot - x) * lo; }
@@ -1157,8 +1159,19 @@ collide_select_kernel(int N, int n_rb, CollideCull cu, const double *__restrict_
       }
       sCmax[gq] = m;
     }
-    if constexpr (kStage)
-      for (int e = threadIdx.x; e < nG * 6; e += kSelThreads) sBox[e] = cu.colbox[e];
+    if constexpr (kStage) {      // (one flight: six loads per thread at most)
+      double bv[kStageGroups * 6 / kSelThreads];
+#pragma unroll
+      for (int u = 0; u < kStageGroups * 6 / kSelThreads; ++u) {
+        const int e = threadIdx.x + u * kSelThreads;
+        bv[u] = e < nG * 6 ? cu.colbox[e] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kStageGroups * 6 / kSelThreads; ++u) {
+        const int e = threadIdx.x + u * kSelThreads;
+        if (e < nG * 6) sBox[e] = bv[u];
+      }
+    }
     __syncthreads();
   }
   auto load_box = [&](int gq, double(&B)[6]) {
@@ -1405,15 +1418,17 @@ constexpr int kGroupLanes = kWave / 2;  // samples per trip
 // device-coherent stores the writer has to wait for, a returning atomic and coherent loads: five memory-side round trips
 // of ~2 us behind every item, against one kernel boundary.)
 constexpr int kFinishWaves = 4;      // groups (wavefronts) per workgroup
+// kChunks (template parameter): 64-entry chunks of a reverse-list row: 8 up to 4096 drones, 16 up to 8192, 32 up to 16 384
+template <int kChunks>
 __global__ void __launch_bounds__(kWave * kFinishWaves)
-collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, CullGroups cg, double radius,
-                             double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit) {
-  constexpr int kChunks = kCullGroupMaxDrones / kColBlock / kWave;
+collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, const int32_t *__restrict__ meta, CullGroups cg,
+                             double radius, double *__restrict__ min_dist, int32_t *__restrict__ partner,
+                             int32_t *__restrict__ hit) {
   __shared__ int sItAll[kFinishWaves][kChunks * kWave];
   const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   int *sIt = sItAll[w];
   const int gq = blockIdx.x * kFinishWaves + w;
-  if (gq >= cg.nG) return;
+  if (gq >= cg.nG || meta[kMetaGroups] > cg.cap) return;      // (more survivors than list slots: the share evaluator runs)
   int pl[kChunks];
 #pragma unroll
   for (int c = 0; c < kChunks; ++c)
@@ -1486,18 +1501,30 @@ collide_eval_groups_kernel(const double *__restrict__ pcol, int N, int S, const 
                            const int32_t *__restrict__ meta, CullGroups cg, unsigned long long *__restrict__ hint) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x;
-  const int tot = meta[kMetaGroups];
+  int tot = meta[kMetaGroups];
   if (blockIdx.x == 0 && lane == 0 && hint != nullptr)
     __hip_atomic_store(hint, cull_hint_pack(N, meta[kMetaTotal], tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tot > cg.cap) tot = 0;      // (more survivors than list slots: the share evaluator behind this launch runs instead)
   const unsigned stride = (unsigned)S * 3u;
+  // XCD-aware item order.  Blocks are dealt round-robin over the 8 XCDs (observed; a speed matter only), so the blocks
+  // b, b + 8, ... share an XCD and its L2: they walk one contiguous eighth of the list.  The list is a-major -- the ~8
+  // items of a group sit side by side and each reads the group's 8 drone rows (17 KB), their column groups are
+  // neighbours in the sorted order -- so most of an item's 35 KB are then hits in its XCD's 4 MB L2; in list order the
+  // eight items of a group went to eight XCDs and every one of them fetched the rows from beyond L2.
+  const int per = (tot + 7) >> 3;
+  auto item_of = [&](int v) { return (v >> 3) < per ? (v & 7) * per + (v >> 3) : tot; };      // (>= tot: none)
   // (the first list entry is fetched beside the survivor count, the next one under the current item)
-  int entry = (int)blockIdx.x < cg.cap ? cg.glist[blockIdx.x] : 0;
-  for (int it = blockIdx.x; it < tot; it += gridDim.x) {
+  int v = blockIdx.x, it = item_of(v);
+  int entry = (it < tot && it < cg.cap) ? cg.glist[it] : 0;
+  for (; (v >> 3) < per; v += gridDim.x, it = item_of(v)) {
+    const int it_next = item_of(v + (int)gridDim.x);
+    const int ent_raw = entry;
+    entry = it_next < tot ? cg.glist[it_next] : 0;
+    if (it >= tot) continue;
     // (the entry is wave-uniform: as a scalar the drones' row bases are scalar too, and every load is base + one lane offset)
-    const int ent = __builtin_amdgcn_readfirstlane(entry);
+    const int ent = __builtin_amdgcn_readfirstlane(ent_raw);
     const int a = ent >> 16, b = ent & 0xffff;
     const bool diag = a == b;
-    entry = it + (int)gridDim.x < tot ? cg.glist[it + gridDim.x] : 0;
 
     // (everything derived from the lane index is rebuilt per phase from an opaque copy: left visible, the values the
     // candidate folds need are computed up front and held through the sample loop, whose 128 registers are spoken for)
@@ -1612,7 +1639,10 @@ __global__ void __launch_bounds__(kWave, 4)
 collide_eval_shares_kernel(const double *__restrict__ prow_t, const double *__restrict__ pcol, CollideGeom g,
                            double *__restrict__ part_d2, int32_t *__restrict__ part_j, double *__restrict__ cpart_d2,
                            int32_t *__restrict__ cpart_i, const int32_t *__restrict__ oid, const int32_t *__restrict__ list,
-                           int sp_force, int slots, int32_t *__restrict__ meta, unsigned long long *__restrict__ hint) {
+                           int sp_force, int slots, int32_t *__restrict__ meta, unsigned long long *__restrict__ hint,
+                           int groups_cap) {
+  // (launched behind the group evaluator of a large swarm: only if the survivors did not fit its list)
+  if (groups_cap > 0 && meta[kMetaGroups] <= groups_cap) return;
   if (blockIdx.x == 0 && threadIdx.x == 0 && hint != nullptr)
     __hip_atomic_store(hint, cull_hint_pack(g.R, meta[kMetaTotal], meta[kMetaGroups]), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1670,7 +1700,9 @@ __global__ void __launch_bounds__(kMergeRows * kMergeParts)
 collide_merge_kernel(const double *__restrict__ part_d2, const int32_t *__restrict__ part_j, CollideGeom g,
                      const double *__restrict__ cpart_d2, const int32_t *__restrict__ cpart_i, double radius,
                      double *__restrict__ min_dist, int32_t *__restrict__ partner, int32_t *__restrict__ hit,
-                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta) {
+                     const int32_t *__restrict__ oid, const int32_t *__restrict__ cnt, const int32_t *__restrict__ meta,
+                     int groups_cap = 0) {
+  if (groups_cap > 0 && meta[kMetaGroups] <= groups_cap) return;      // (the group evaluator's fold wrote the results)
   __shared__ double sD[kMergeParts][kMergeRows];
   __shared__ int sJ[kMergeParts][kMergeRows];
   const int lr = threadIdx.x & (kMergeRows - 1), q = threadIdx.x / kMergeRows;
@@ -1895,12 +1927,6 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
                     unsigned long long *__restrict__ bound, int32_t *__restrict__ zero, int n_zero,
                     int32_t *__restrict__ meta) {
   __shared__ int cnt[kRankWaves][kRankTile];
-  // (a tile drone's box is fetched up front: it only decides where the drone's bound starts)
-  bool has = false;
-  if (threadIdx.x < kRankTile && (int)(blockIdx.x * kRankTile + threadIdx.x) < N) {
-    const double *bx = box + (size_t)(blockIdx.x * kRankTile + threadIdx.x) * 6;
-    has = (bx[0] <= bx[3]) & (bx[1] <= bx[4]) & (bx[2] <= bx[5]);
-  }
   {
     const int gid = blockIdx.x * (kWave * kRankWaves) + threadIdx.x;
     for (int z = gid; z < n_zero; z += gridDim.x * (kWave * kRankWaves)) zero[z] = 0;
@@ -1911,20 +1937,34 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
   }
   const int lane = threadIdx.x & (kWave - 1), w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int nq = (N + kRankWaves * kWave - 1) / (kRankWaves * kWave);      // words per lane
+  // All of a lane's words and the tile's 16 keys are ONE flight of loads (unconditional, clamped addresses; masked
+  // afterwards): written with the bounds tests around the loads, every word and every tile key was its own load-and-
+  // wait -- 20 dependent round trips, two thirds of the kernel's 7.5 us.  The tile keys travel as one vector load and
+  // are handed out with readlane.
+  const int i0 = blockIdx.x * kRankTile;
+  unsigned kraw[kRankKeys];
+#pragma unroll
+  for (int q = 0; q < kRankKeys; ++q) {
+    const int j = (w * nq + q) * kWave + lane;
+    kraw[q] = key[(q < nq && j < N) ? j : 0];
+  }
+  const unsigned ktile = key[i0 + (lane & (kRankTile - 1)) < N ? i0 + (lane & (kRankTile - 1)) : N - 1];
+  // (a tile drone's box travels in the same flight: it only decides where the drone's bound starts)
+  double bx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (threadIdx.x < kRankTile && i0 + (int)threadIdx.x < N) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bx[k] = box[(size_t)(i0 + threadIdx.x) * 6 + k];
+  }
   unsigned long long mine[kRankKeys];
 #pragma unroll
   for (int q = 0; q < kRankKeys; ++q) {
-    mine[q] = ~0ull;      // (~0: below nothing)
-    if (q < nq) {         // (wave-uniform: a swarm of 4096 has 4 of the 16 words)
-      const int j = (w * nq + q) * kWave + lane;
-      if (j < N) mine[q] = ((unsigned long long)key[j] << 32) | (unsigned)j;
-    }
+    const int j = (w * nq + q) * kWave + lane;
+    mine[q] = (q < nq && j < N) ? ((unsigned long long)kraw[q] << 32) | (unsigned)j : ~0ull;      // (~0: below nothing)
   }
-  const int i0 = blockIdx.x * kRankTile;
 #pragma unroll
   for (int t = 0; t < kRankTile; ++t) {
     const int i = i0 + t < N ? i0 + t : N - 1;      // wave-uniform
-    const unsigned long long ki = ((unsigned long long)key[i] << 32) | (unsigned)i;
+    const unsigned long long ki = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ktile, t) << 32) | (unsigned)i;
     int c = 0;
 #pragma unroll
     for (int q = 0; q < kRankKeys; ++q)
@@ -1938,6 +1978,7 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
     for (int q = 0; q < kRankWaves; ++q) r += cnt[q][threadIdx.x];
     const int i = i0 + threadIdx.x;
     perm[r] = i;
+    const bool has = (bx[0] <= bx[3]) & (bx[1] <= bx[4]) & (bx[2] <= bx[5]);
     bound[r] = has ? 0x7ff0000000000000ull : 0ull;
   }
 }
@@ -2001,12 +2042,25 @@ collide_gather_kernel(const double *__restrict__ pos, int N, int Rp, int E, doub
   const int bx = blockIdx.x % nx, by = blockIdx.x / nx;
   const int r0 = bx * kTileRows, e0 = by * kTileE;
   const int ne = E - e0 < kTileE ? E - e0 : kTileE;      // whole samples: E and kTileE are multiples of 3
-  for (int idx = tid; idx < (kTileRows + kTileHalo) * kTileE; idx += 256) {
-    const int i = idx / kTileE, tx = idx - i * kTileE;
-    const int r = r0 + i < N ? r0 + i : N - 1;
-    const double v = tx < ne ? pos[(size_t)perm[r] * E + e0 + tx] : 0.0;
-    tile[i * kTilePitch + tx] = v;
-    if (i < kTileRows && tx < ne && r0 + i < N) psorted[(size_t)r * E + e0 + tx] = v;
+  // the tile's rows of the permutation first (one round trip), then every thread's elements in ONE flight: written as
+  // a plain loop each element was permutation load, wait, position load, wait -- eight dependent round trips per thread
+  __shared__ int sPerm[kTileRows + kTileHalo];
+  if (tid < kTileRows + kTileHalo) sPerm[tid] = perm[r0 + tid < N ? r0 + tid : N - 1];
+  __syncthreads();
+  constexpr int kElems = (kTileRows + kTileHalo) * kTileE, kPer = (kElems + 255) / 256;
+  double val[kPer];
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int idx = tid + u * 256, i = idx / kTileE, tx = idx - i * kTileE;
+    val[u] = (idx < kElems && tx < ne) ? pos[(size_t)sPerm[i] * E + e0 + tx] : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int idx = tid + u * 256, i = idx / kTileE, tx = idx - i * kTileE;
+    if (idx < kElems) {
+      tile[i * kTilePitch + tx] = val[u];
+      if (i < kTileRows && tx < ne && r0 + i < N) psorted[(size_t)(r0 + i) * E + e0 + tx] = val[u];
+    }
   }
   __syncthreads();
   {
@@ -2039,7 +2093,8 @@ collide_gather_kernel(const double *__restrict__ pos, int N, int Rp, int E, doub
 
 // what the cost model makes of a pass's survivor counts (the choice the NEXT pass of this swarm takes from the hint)
 bool collide_counts_by_groups(const msnap_ctx *ctx, int n_drones, int shares_surviving, int group_pairs_surviving) {
-  if (ctx->collide_cull_mode == 1 || n_drones > kCullGroupMaxDrones) return false;
+  if (ctx->collide_cull_mode == 1) return false;
+  if (n_drones > kCullGroupMaxDrones && 2LL * group_pairs_surviving > kGroupCapLarge) return false;
   if (ctx->collide_cull_mode == 2) return true;
   return cull_groups_cheaper(shares_surviving, group_pairs_surviving);
 }
@@ -2167,16 +2222,21 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     long long shares = 0;
     for (int I = 0; I < g.n_rb; ++I) shares += (N - I * kRowBlock + kColBlock - 1) / kColBlock;
     const long long all_groups = (long long)nJ * (nJ + 1) / 2;
-    const bool groups_fit = N <= kCullGroupMaxDrones;
+    // Up to kCullGroupMaxDrones every group pair has a list slot; larger swarms get kGroupCapLarge slots and BOTH
+    // evaluators are launched -- the share evaluator and its merge return at once unless the survivors overflowed the
+    // list (then the group launches did nothing): two empty launches on a pass of a quarter millisecond.
+    const bool all_fit = N <= kCullGroupMaxDrones;
     bool by_groups = false;
     if (ctx->collide_cull_mode == 2) {
-      by_groups = groups_fit;
-    } else if (ctx->collide_cull_mode != 1 && groups_fit && ctx->cull_hint) {
+      by_groups = true;
+    } else if (ctx->collide_cull_mode != 1 && ctx->cull_hint) {
       const unsigned long long h = *(volatile unsigned long long *)ctx->cull_hint;
       const int hN = (int)(h >> 48) & 0x7fff;
       const long long hs = (long long)((h >> 24) & 0xffffff), hg = (long long)(h & 0xffffff);
-      by_groups = h != 0 && hN == N && hg != 0xffffff && cull_groups_cheaper(hs, hg);
+      by_groups = h != 0 && hN == (N & 0x7fff) && hg != 0xffffff && cull_groups_cheaper(hs, hg) &&
+                  (all_fit || 2 * hg <= kGroupCapLarge);
     }
+    const bool both = by_groups && !all_fit;
     // sample parts a share may be cut into: the column-side slots are n_rb x spmax x N entries, pre-filled per call
     const int spmax = N > 8192 ? 2 : kCullMaxParts;
     ctx->collide_last_shares = (int)shares;
@@ -2185,9 +2245,9 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     // share evaluator: row-side entries, one per item (cull_split cuts shares only while the items stay below twice the
     // wave slots), column-side slots.  Group evaluator: list, 16 candidate slots per item, reverse lists
     const long long items_max = (sp_force & 0xff) ? shares * (sp_force & 0xff) : (shares > 2 * slots ? shares : 2 * slots);
-    const size_t entries = by_groups ? 0 : (size_t)items_max * kRowBlock;
-    const size_t centries = by_groups ? 0 : (size_t)g.n_rb * spmax * N;
-    const size_t gcap = by_groups ? (size_t)all_groups : 0;
+    const size_t entries = (by_groups && !both) ? 0 : (size_t)items_max * kRowBlock;
+    const size_t centries = (by_groups && !both) ? 0 : (size_t)g.n_rb * spmax * N;
+    const size_t gcap = !by_groups ? 0 : all_fit ? (size_t)all_groups : (size_t)kGroupCapLarge;
     // the sampler's hand-over (msnap_sample_collide_device: boxes [N][6], then keys [N]) saves the key launch
     const bool have_keys = handover_form(ctx, rows_t_in, N, n_samples) == 2;
     // Buffers (doubles, then ints): sorted row image [E][Rp] | sorted columns [N][E] | box [N][6] | colbox [nJ][6] |
@@ -2222,7 +2282,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
     ctx->blist_clean_n = (int)nJ;
     ctx->collide_meta = meta;
     ctx->collide_last_cull = 1;
-    ctx->collide_last_by_groups = by_groups ? 1 : 0;
+    ctx->collide_last_by_groups = by_groups ? (all_fit ? 1 : 2) : 0;      // (2: while the survivors fit kGroupCapLarge)
     ctx->collide_last_n = N;
     if (!have_keys) {
       hipLaunchKernelGGL(collide_key_kernel, dim3((N + kKeyDrones - 1) / kKeyDrones), dim3(kWave * kKeyDrones), 0,
@@ -2234,7 +2294,7 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
                        bound, blist, (int)(by_groups && !blist_clean ? nJ * nJ : 0), meta);
     MSNAP_HIP(ctx, hipGetLastError());
     const int nx = g.Rp / kTileRows, ny = (E + kTileE - 1) / kTileE;
-    const int n_box = (int)((nJ + kBoxGroups - 1) / kBoxGroups), n_fill = by_groups ? 0 : 4 * nx;
+    const int n_box = (int)((nJ + kBoxGroups - 1) / kBoxGroups), n_fill = centries ? 4 * nx : 0;
     hipLaunchKernelGGL(collide_gather_kernel, dim3((unsigned)(nx * ny + n_box + n_fill)), dim3(256), 0, ctx->stream, pos_cols, N,
                        g.Rp, E, rows_t, psorted, (const int32_t *)perm, bound, box, colbox, nx, ny, n_box, ci, centries);
     MSNAP_HIP(ctx, hipGetLastError());
@@ -2247,18 +2307,20 @@ int launch_formation_collide(msnap_ctx *ctx, int n_rows, int row_offset, int n_c
       hipLaunchKernelGGL(collide_eval_groups_kernel, dim3((unsigned)(ctx->n_cu * 4 * kGroupWaves)), dim3(kWave), 0, ctx->stream,
                          (const double *)psorted, N, n_samples, (const int32_t *)perm, (const int32_t *)meta, cg, ctx->cull_hint);
       MSNAP_HIP(ctx, hipGetLastError());
-      hipLaunchKernelGGL(collide_finish_groups_kernel, dim3((unsigned)((nJ + kFinishWaves - 1) / kFinishWaves)),
-                         dim3(kWave * kFinishWaves), 0, ctx->stream, N, (const int32_t *)perm, cg, radius, min_dist, partner, hit);
+      hipLaunchKernelGGL((N <= 4096 ? collide_finish_groups_kernel<8> : N <= 8192 ? collide_finish_groups_kernel<16> : collide_finish_groups_kernel<32>),
+                         dim3((unsigned)((nJ + kFinishWaves - 1) / kFinishWaves)),
+                         dim3(kWave * kFinishWaves), 0, ctx->stream, N, (const int32_t *)perm, (const int32_t *)meta, cg, radius,
+                         min_dist, partner, hit);
       MSNAP_HIP(ctx, hipGetLastError());
-      return MSNAP_OK;
+      if (!both) return MSNAP_OK;
     }
     hipLaunchKernelGGL(collide_eval_shares_kernel, dim3((unsigned)slots), dim3(kWave), 0, ctx->stream, (const double *)rows_t,
                        (const double *)psorted, g, pd, pj, cd, ci, (const int32_t *)perm, (const int32_t *)surv, sp_force,
-                       (int)slots, meta, ctx->cull_hint);
+                       (int)slots, meta, ctx->cull_hint, both ? (int)gcap : 0);
     MSNAP_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(collide_merge_kernel, dim3((N + kMergeRows - 1) / kMergeRows), dim3(kMergeRows * kMergeParts), 0,
                        ctx->stream, pd, pj, g, cd, ci, radius, min_dist, partner, hit, (const int32_t *)perm,
-                       (const int32_t *)cnt, (const int32_t *)meta);
+                       (const int32_t *)cnt, (const int32_t *)meta, both ? (int)gcap : 0);
     MSNAP_HIP(ctx, hipGetLastError());
     return MSNAP_OK;
   }

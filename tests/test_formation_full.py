@@ -282,6 +282,28 @@ def test_broad_phase_equals_the_full_pass(ctx7, kind, n, S):
 
 
 @pytest.mark.gpu
+def test_large_swarm_group_list_overflow_falls_back_to_the_shares(ctx7):
+    """Swarms above 8192 drones get 2^18 group-pair list slots and both evaluators are launched: the share evaluator and
+    its merge return at once unless the survivors overflowed the list.  A sparse swarm goes through the group pairs, a
+    dense one (652 653 group pairs, all surviving) overflows -- both equal to the oracle."""
+    rng = np.random.default_rng(31)
+    n, S = 9136, 6
+    ctx7.set_option("collide_cull_mode", 2)
+    try:
+        for kind, by_groups in (("sparse", 1), ("dense", 0)):
+            pos = _broad_phase_swarm(kind, n, S, rng)
+            ref = c_oracle.formation_collide(pos, 0.3)
+            got = ctx7.formation_collide(pos, pos, 0.3)
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b)
+            assert ctx7.get_option("collide_last_cull") == 1
+            assert ctx7.get_option("collide_last_by_groups") == by_groups
+            assert (ctx7.get_option("collide_last_group_pairs") > (1 << 18)) == (not by_groups)
+    finally:
+        ctx7.set_option("collide_cull_mode", 0)
+
+
+@pytest.mark.gpu
 def test_evaluator_choice_follows_the_previous_pass():
     """"collide_cull_mode" 0: which evaluator runs behind the broad phase is a host decision (the launch sequences
     differ: the group pairs finish inside their evaluator, the shares are followed by a merge), taken from the survivor
