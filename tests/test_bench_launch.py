@@ -34,6 +34,15 @@ def test_plain_gpus_2_starts_two_ranks():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["ranks_counted_by_all_reduce"] == 2 and d["backend"] == "gloo"
 
 
+def test_plain_gpus_8_starts_eight_ranks():
+    """the driver's largest case as far as a CPU box can take it: eight ranks, one all-reduce over all of them"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--launch-check"],
+                       capture_output=True, text=True, timeout=600, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_lines(r.stdout)[0]
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["ranks_counted_by_all_reduce"] == 8
+
+
 def test_under_torchrun_the_flag_must_match_world_size():
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
             "--master-port", "29631", BENCH, "--backend", "gloo", "--launch-check"]
