@@ -415,9 +415,10 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(nst + 1)] for _ in range(reps)]
     set_stages()
 
-    def one(rec, overlap):
+    def one(rec, overlap, fused=False):
         """one pipeline; `overlap`: the mesh sweep on the side stream next to the exchange and the pairwise
-        pass (what is timed as the pipeline), else everything in stream order (what the stage times are)"""
+        pass (what is timed as the pipeline), else everything in stream order (what the stage times are);
+        `fused`: solve and sampler through msnap_solve_grid_sample_device (one launch up to 11 segments)"""
         k = 0
 
         def mark():
@@ -426,13 +427,16 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                 rec[k].record()
             k += 1
         mark()
-        coef, dur, status = comp.solve_grid(twp)      # the swarm shares the reference's uniform grid: K2
-        mark()
         rows_t = None
-        if world == 1:      # the sampler also writes the transposed row image, if the pairwise pass is going to read it
-            pos, rows_t = comp.sample_rows_t(coef, dur, synthetic.SAMPLE_DT, S, n_cols=N)
+        if fused:
+            coef, dur, status, pos, rows_t = comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
         else:
-            pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
+            coef, dur, status = comp.solve_grid(twp)      # the swarm shares the reference's uniform grid: K2
+            mark()
+            if world == 1:      # the sampler also writes its hand-over to the pairwise pass, if that is going to read it
+                pos, rows_t = comp.sample_rows_t(coef, dur, synthetic.SAMPLE_DT, S, n_cols=N)
+            else:
+                pos = comp.sample(coef, dur, synthetic.SAMPLE_DT, S)
         mark()
         try:
             if tris is not None and overlap:
@@ -460,16 +464,16 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
             comp.mesh_abort()       # joins the side stream if something above raised between begin and end
         return status, hit, mh, md, pos
 
-    def timed(overlap, recs):
+    def timed(overlap, recs, fused=False):
         for _ in range(warm):
-            one(None, overlap)
+            one(None, overlap, fused)
         torch.cuda.synchronize()
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for r in range(reps):
-            out = one(recs[r] if recs else None, overlap)
+            out = one(recs[r] if recs else None, overlap, fused)
         torch.cuda.synchronize()
         w = time.perf_counter() - t0
         if use_pg:
@@ -493,7 +497,22 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     # pass 2: the pipeline as it is run -- no events between the stages, and (configs[3]) the mesh sweep beside the
     # exchanges and the pairwise pass
     wall_serial = wall
-    wall, (status, hit, mh, md, pos_keep) = timed(tris is not None, None)
+    stage_out = [x.clone() for x in (status, hit, md, pos_keep)]
+    wall, (status, hit, mh, md, pos_keep) = timed(tris is not None, None, fused=True)
+    fused_kernel = None
+    # the fused launch on its own (and that it gives the separate stages' results bit for bit)
+    for a, b in zip(stage_out, (status, hit, md, pos_keep)):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), "fused solve + sampler differs from the two stages"
+    for _ in range(3):
+        comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
+    fused_kernel = ctx.last_kernel()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
+    e1.record()
+    torch.cuda.synchronize()
+    fused_us = e0.elapsed_time(e1) / reps * 1e3
     # the per-drone-grid kernel (K1: any time grids) on the same shard, outside the pipeline
     for _ in range(3):
         comp.solve(twp, tt)
@@ -524,12 +543,14 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     comp.close()                 # drops the wrapper of the side stream before its context goes
     if side_ctx is not None:
         side_ctx.close()
-    mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial], red_dev, use_pg)
+    mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial, fused_us], red_dev, use_pg)
     cnt = sum_over_ranks(torch, dist, [int(status.abs().sum().item()), int(hit.sum().item()),
                                        int(mh.sum().item()) if mh is not None else 0], red_dev, use_pg)
     if rank != 0:
         return None
     wall_max, st, gemm, wall_serial_max = mx[0], dict(zip(stage_names, mx[1:1 + nst])), mx[1 + nst], mx[2 + nst]
+    fused_max = mx[3 + nst]
+    is_fused = fused_kernel.startswith("msnap::grid_sample_kernel")
     per = wall_max / reps
     fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz")) if n_groups == 512 else None
     n_max = max(swarm.shard_sizes(N, world))
@@ -548,7 +569,9 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                     ("; the pairwise pass on the whole gathered swarm on every rank" if whole else "") + ")", "rccl_ranks": world,
         "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": st,
-        "stage_us_note": "stages timed in stream order (events between them); us_per_pipeline from a second pass without them" + (
+        "stage_us_note": "stages timed in stream order (events between them), solve and sampler as separate launches; "
+                         "us_per_pipeline from a second pass without events" + (
+            ", in which solve and sampler are the one fused launch of stages.solve_sample" if is_fused else "") + (
             "; us_per_pipeline is the pipeline as run: the mesh sweep on a side stream beside the "
             f"{'all-gather and the ' if world > 1 else ''}pairwise pass ({wall_serial_max / reps * 1e6:.1f} us in stream order)"
             if tris is not None else ""),
@@ -565,6 +588,15 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                           "time grids takes), outside the pipeline time"},
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+            "solve_sample": {"kernel": fused_kernel if is_fused else fused_kernel + " + msnap::sample_kernel",
+                             "fused": is_fused, "us": fused_max, "separate_us": st["solve"] + st["sample"], "bound": "hbm",
+                             # one launch: waypoints in; coefficients, durations, status and positions out (the
+                             # sampler's read-back of the coefficients stays in LDS)
+                             "frac": (algorithmic_bytes(n_max, M, order) + n_max * S * 24) / (fused_max * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "note": "msnap_solve_grid_sample_device, what the pipeline as run uses: the fp64 MFMA "
+                                     "product and the Horner loops in one launch up to 11 segments (coefficients through "
+                                     "LDS, outputs bit-identical to the two stages -- asserted here on every run); longer "
+                                     "paths gain nothing from it and run the two kernels"},
             "pairwise": {"kernel": (("msnap::" + ("" if world == 1 else "collide_key_kernel + ") + "collide_rank_kernel + "
                                      "collide_gather_kernel + collide_select_kernel + " +
                                      ("collide_eval_groups_kernel + collide_finish_groups_kernel (exact broad phase; the pass's "

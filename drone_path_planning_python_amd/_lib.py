@@ -62,6 +62,7 @@ SIGNATURES = {
     "msnap_collide_rows_t_doubles": (ctypes.c_size_t, [_I, _I]),
     "msnap_formation_collide_reads_rows_t": (_I, [_VP, _I, _I, _I, _I]),
     "msnap_sample_collide_device": (_I, [_VP, _I, _I, _VP, _VP, _D, _I, _VP, _VP]),
+    "msnap_solve_grid_sample_device": (_I, [_VP, _I, _I, _VP, _D, _I, _VP, _VP, _VP, _VP, _VP]),
     "msnap_formation_collide_t_device": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _VP, _D, _VP, _VP, _VP]),
     "msnap_formation_part_bytes": (ctypes.c_size_t, [_I]),
     "msnap_formation_collide_takes_broad_phase": (_I, [_VP, _I, _I, _I, _I]),

@@ -405,6 +405,14 @@ class Context:
             self._ck(self._lib.msnap_sample_collide_device(self._h, int(n_drones), int(n_seg), _ptr(coef), _ptr(dur),
                                                           float(dt), int(n_samples), _ptr(pos), _ptr(pos_t)))
 
+    def solve_grid_sample_device(self, n_drones, n_seg, wp, dt, n_samples, coef, dur, status, pos, pos_t=None):
+        """The shared-grid solve and the sampler as one launch (msnap.h): the outputs of solve_grid_device followed by
+        sample_collide_device (`pos_t` given) or the 3-axis sampler, bit for bit."""
+        with self._lock:
+            self._ck(self._lib.msnap_solve_grid_sample_device(
+                self._h, int(n_drones), int(n_seg), _ptr(wp), float(dt), int(n_samples), _ptr(coef), _ptr(dur),
+                _ptr(status), _ptr(pos), _ptr(pos_t) if pos_t is not None else None))
+
     def formation_collide_t_device(self, n_rows, row_offset, n_cols, n_samples, pos_rows_t, pos_rows, pos_cols, radius,
                                    min_dist, partner, hit):
         with self._lock:

@@ -78,7 +78,7 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"collide_cull_mode", "MSNAP_COLLIDE_CULL_MODE"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"no_grid_sample", "MSNAP_NO_GRID_SAMPLE"}, {"gemm_stream_waves_per_cu", "MSNAP_GEMM_STREAM_WAVES_PER_CU"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"collide_cull_mode", "MSNAP_COLLIDE_CULL_MODE"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
 };
 
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
@@ -96,6 +96,8 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "twist_max_drones")) return &ctx->twist_max_drones;
   if (!strcmp(name, "no_twist")) return &ctx->no_twist;
   if (!strcmp(name, "no_twin")) return &ctx->no_twin;
+  if (!strcmp(name, "no_grid_sample")) return &ctx->no_grid_sample;
+  if (!strcmp(name, "gemm_stream_waves_per_cu")) return &ctx->gemm_stream_waves_per_cu;
   if (!strcmp(name, "twin_max_drones")) return &ctx->twin_max_drones;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;
@@ -705,6 +707,28 @@ int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const d
   if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
   *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
   return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, 3, pos, pos_t, keys);
+}
+
+int msnap_solve_grid_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double dt, int n_samples,
+                                   double *coef, double *dur, int32_t *status, double *pos, double *pos_t) {
+  if (!sample_args_ok(ctx, n_drones, n_samples, 3, dt)) return MSNAP_EINVAL;
+  if (!ctx->grid_ready) return MSNAP_ENOGRID;
+  if (n_seg != ctx->grid_seg) return MSNAP_ESEGMENTS;
+  if (n_drones == 0) return MSNAP_OK;
+  if (!wp || !coef || !dur || !status) return MSNAP_EINVAL;
+  MSNAP_HIP(ctx, hipSetDevice(ctx->device));
+  if (n_samples == 0) return launch_solve_grid(ctx, n_drones, wp, coef, dur, status);
+  if (!pos) return MSNAP_EINVAL;
+  bool keys = false;
+  if (pos_t) {      // the hand-over to the pairwise pass, as msnap_sample_collide_device records it
+    keys = formation_collide_takes_broad_phase(ctx, n_drones, 0, n_drones, n_samples);
+    msnap_ctx::Handover *rec = nullptr;
+    for (auto &h : ctx->handover)
+      if (h.ptr == (const void *)pos_t) rec = &h;
+    if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
+    *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
+  }
+  return launch_grid_sample(ctx, n_drones, wp, dt, n_samples, coef, dur, status, pos, pos_t, keys);
 }
 
 int msnap_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur, double dt,

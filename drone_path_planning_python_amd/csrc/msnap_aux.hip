@@ -182,7 +182,8 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask);
 // dt == 0 and for paths whose samples do not fit the LDS image of the fast kernel.
 template <int NC>
 __device__ __forceinline__ void sample_point_generic(const double *__restrict__ coef, const double *__restrict__ dr,
-                                                     int M, double t, int a, double &x) {
+                                                     int M, double t, int a, double &x, int seg_stride = 4 * NC,
+                                                     int axis_stride = NC) {
 #pragma clang fp contract(off)
   double acc = 0.0;
   int seg = M - 1;
@@ -197,7 +198,7 @@ __device__ __forceinline__ void sample_point_generic(const double *__restrict__ 
   }
   // not found: acc == sum(dur[:-1]) and seg == M-1 (uav_trajectory.py:161-163)
   const double tl = t - acc;
-  const double *c = coef + ((size_t)seg * 4 + a) * NC;
+  const double *c = coef + (size_t)seg * seg_stride + (size_t)a * axis_stride;
   x = 0.0;
 #pragma unroll
   for (int q = NC - 1; q >= 0; --q) x = x * tl + c[q];
@@ -230,6 +231,99 @@ sample_generic_kernel(const double *__restrict__ coef, const double *__restrict_
 // sample and gates the coefficient address behind M dependent duration loads: 34 % of the HBM rate).
 // A workgroup owns DW whole drones; results go through an LDS image of their [S][naxes] blocks and
 // leave as 16-byte-per-lane runs (direct 8-byte stores at a 24-byte stride reach L2 as 21-byte requests).
+// the samples of one (drone, piece, axis): s_lo .. s_hi - 1 from the running sums, Horner on the piece's row (`load`
+// fills it once the range is known to be non-empty)
+template <int NC, class Load>
+__device__ __forceinline__ void sample_piece(double bi, double bn, int i, int M, int S, double dt, double *img,
+                                             int naxes, int a, Load load) {
+#pragma clang fp contract(off)
+  // first sample with fl(s*dt) >= b: the quotient is a guess, the products decide
+  auto first_at = [&](double b) -> int {
+    const double x = b / dt;
+    int c = x >= (double)S ? S : (int)x;
+    while (c > 0 && (double)(c - 1) * dt >= b) --c;
+    while (c < S && (double)c * dt < b) ++c;
+    return c;
+  };
+  const int s_lo = (i == 0) ? 0 : first_at(bi);
+  const int s_hi = (i == M - 1) ? S : first_at(bn);
+  if (s_lo >= s_hi) return;
+  double c[NC];
+  load(c);
+  for (int sq = s_lo; sq < s_hi; ++sq) {
+    const double tl = (double)sq * dt - bi;
+    double x = 0.0;
+#pragma unroll
+    for (int q = NC - 1; q >= 0; --q) x = x * tl + c[q];
+    img[(size_t)sq * naxes + a] = x;
+  }
+}
+
+// the finished LDS image [nd][S][naxes] of a workgroup's drones d0 .. d0 + nd - 1 -> pos, and the second output
+__device__ __forceinline__ void sample_image_out(const double *sImg, int tid, int nthreads, int nd, int d0,
+                                                 size_t per_drone, int S, double *__restrict__ pos,
+                                                 double *__restrict__ pos_t, int Rp, double *__restrict__ kbox,
+                                                 unsigned *__restrict__ kkey) {
+  // the nd drones' blocks are contiguous in pos: 16 bytes per lane (per_drone * nd doubles; odd tail by one lane)
+  const size_t words = per_drone * nd;
+  double *out = pos + (size_t)d0 * per_drone;
+  const bool aligned = ((size_t)d0 * per_drone & 1) == 0;
+  if (aligned) {
+    for (size_t e = (size_t)tid * 2; e + 1 < words; e += (size_t)nthreads * 2)
+      *reinterpret_cast<double2 *>(out + e) = *reinterpret_cast<const double2 *>(sImg + e);
+    if ((words & 1) && tid == 0) out[words - 1] = sImg[words - 1];
+  } else {
+    for (size_t e = tid; e < words; e += nthreads) out[e] = sImg[e];
+  }
+  // second output for the pairwise pass (msnap_sample_collide): the same samples as the transposed row image
+  // [sample][xyz][row] (row pitch Rp) that collide_span_kernel reads -- the workgroup's DW drones are DW
+  // consecutive rows, so every (sample, axis) is one run of DW doubles -- instead of a transposition pass
+  // over the finished positions
+  if (pos_t != nullptr) {
+    const int runs = (int)per_drone;              // (sample, axis) pairs; naxes == 3 (checked by the launcher)
+    for (int e = tid; e < runs * nd; e += nthreads) {
+      const int sk = e / nd, dl = e - sk * nd;
+      pos_t[(size_t)sk * Rp + d0 + dl] = sImg[(size_t)dl * per_drone + sk];
+    }
+  }
+  // third output, for a whole-swarm pass behind the exact broad phase: what collide_key_kernel would compute from
+  // the finished positions -- the box of the drone's finite samples and its sort key -- while the samples sit in
+  // the image: 16 threads per drone (DW <= 16, naxes == 3), folded inside their 16 lanes
+  if (kbox != nullptr) {
+    const int dl = tid >> 4, part = tid & 15;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (dl < nd) {
+      const double *img = sImg + (size_t)dl * per_drone;
+      for (int sq = part; sq < S; sq += 16)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double v = img[(size_t)sq * 3 + k];
+          if (__builtin_isfinite(v)) {
+            lo[k] = v < lo[k] ? v : lo[k];
+            hi[k] = v > hi[k] ? v : hi[k];
+          }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double ol = shfl_xor_f64(lo[k], m), oh = shfl_xor_f64(hi[k], m);
+        lo[k] = ol < lo[k] ? ol : lo[k];
+        hi[k] = oh > hi[k] ? oh : hi[k];
+      }
+    if (dl < nd && part == 0) {
+      double *b = kbox + (size_t)(d0 + dl) * 6;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b[k] = lo[k];
+        b[3 + k] = hi[k];
+      }
+      kkey[d0 + dl] = drone_sort_key(lo, hi);
+    }
+  }
+}
+
 template <int NC>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
@@ -271,95 +365,237 @@ sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, d
             sample_point_generic<NC>(cbase, dur + (size_t)(d0 + dl) * M, M, (double)sq * dt, a, img[(size_t)sq * naxes + a]);
         continue;
       }
-      const double bi = sB[dl * (M + 1) + i], bn = sB[dl * (M + 1) + i + 1];
-      // first sample with fl(s*dt) >= b: the quotient is a guess, the products decide
-      auto first_at = [&](double b) -> int {
-        const double x = b / dt;
-        int c = x >= (double)S ? S : (int)x;
-        while (c > 0 && (double)(c - 1) * dt >= b) --c;
-        while (c < S && (double)c * dt < b) ++c;
-        return c;
-      };
-      const int s_lo = (i == 0) ? 0 : first_at(bi);
-      const int s_hi = (i == M - 1) ? S : first_at(bn);
-      if (s_lo >= s_hi) continue;
-      double c[NC];
       const double *crow = cbase + ((size_t)i * 4 + a) * NC;
+      sample_piece<NC>(sB[dl * (M + 1) + i], sB[dl * (M + 1) + i + 1], i, M, S, dt, img, naxes, a, [&](double (&c)[NC]) {
 #pragma unroll
-      for (int q = 0; q < NC; q += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(crow + q);
-        c[q] = v.x;
-        c[q + 1] = v.y;
-      }
-      for (int sq = s_lo; sq < s_hi; ++sq) {
-        const double tl = (double)sq * dt - bi;
-        double x = 0.0;
-#pragma unroll
-        for (int q = NC - 1; q >= 0; --q) x = x * tl + c[q];
-        img[(size_t)sq * naxes + a] = x;
-      }
+        for (int q = 0; q < NC; q += 2) {
+          const double2 v = *reinterpret_cast<const double2 *>(crow + q);
+          c[q] = v.x;
+          c[q + 1] = v.y;
+        }
+      });
     }
     __syncthreads();
-    // the nd drones' blocks are contiguous in pos: 16 bytes per lane (per_drone * nd doubles; odd tail by one lane)
-    const size_t words = per_drone * nd;
-    double *out = pos + (size_t)d0 * per_drone;
-    const bool aligned = ((size_t)d0 * per_drone & 1) == 0;
-    if (aligned) {
-      for (size_t e = (size_t)tid * 2; e + 1 < words; e += (size_t)blockDim.x * 2)
-        *reinterpret_cast<double2 *>(out + e) = *reinterpret_cast<const double2 *>(sImg + e);
-      if ((words & 1) && tid == 0) out[words - 1] = sImg[words - 1];
-    } else {
-      for (size_t e = tid; e < words; e += blockDim.x) out[e] = sImg[e];
-    }
-    // second output for the pairwise pass (msnap_sample_collide): the same samples as the transposed row image
-    // [sample][xyz][row] (row pitch Rp) that collide_span_kernel reads -- the workgroup's DW drones are DW
-    // consecutive rows, so every (sample, axis) is one run of DW doubles -- instead of a transposition pass
-    // over the finished positions
-    if (pos_t != nullptr) {
-      const int runs = (int)per_drone;              // (sample, axis) pairs; naxes == 3 (checked by the launcher)
-      for (int e = tid; e < runs * nd; e += blockDim.x) {
-        const int sk = e / nd, dl = e - sk * nd;
-        pos_t[(size_t)sk * Rp + d0 + dl] = sImg[(size_t)dl * per_drone + sk];
-      }
-    }
-    // third output, for a whole-swarm pass behind the exact broad phase: what collide_key_kernel would compute from
-    // the finished positions -- the box of the drone's finite samples and its sort key -- while the samples sit in
-    // the image: 16 threads per drone (DW <= 16, naxes == 3), folded inside their 16 lanes
-    if (kbox != nullptr) {
-      const int dl = tid >> 4, part = tid & 15;
-      double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-      if (dl < nd) {
-        const double *img = sImg + (size_t)dl * per_drone;
-        for (int sq = part; sq < S; sq += 16)
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double v = img[(size_t)sq * 3 + k];
-            if (__builtin_isfinite(v)) {
-              lo[k] = v < lo[k] ? v : lo[k];
-              hi[k] = v > hi[k] ? v : hi[k];
-            }
-          }
-      }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double ol = shfl_xor_f64(lo[k], m), oh = shfl_xor_f64(hi[k], m);
-          lo[k] = ol < lo[k] ? ol : lo[k];
-          hi[k] = oh > hi[k] ? oh : hi[k];
-        }
-      if (dl < nd && part == 0) {
-        double *b = kbox + (size_t)(d0 + dl) * 6;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          b[k] = lo[k];
-          b[3 + k] = hi[k];
-        }
-        kkey[d0 + dl] = drone_sort_key(lo, hi);
-      }
-    }
+    sample_image_out(sImg, tid, blockDim.x, nd, d0, per_drone, S, pos, pos_t, Rp, kbox, kkey);
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------
+// Shared-grid solve and sampler in one launch (msnap_solve_grid_sample_device): a workgroup owns the sampler's DW
+// drones, builds their coefficients as grid_gemm_kernel does -- the same fp64 MFMA chain over the same packed operator
+// fragments, so the coefficients are its bit for bit -- into LDS, writes them out, and samples from LDS.  What it
+// saves is the dependent launch and the coefficient read-back between the two kernels (4.6 us of a 15 us pair at
+// 4096 drones x 10 segments); the waypoints [DW][M+1][4] are staged transposed through LDS as the A operand.
+//   tasks = (row tile of 4 drones) x (column tile of 16 coefficients), wave w takes tasks w, w + 4, ...:
+//   at most kFuseTasks per wave and kFuseKS k steps (M <= 11), or the launcher runs the two kernels.  Longer paths
+//   gain nothing: the product grows with M^2 while the saved launch does not (4096 drones: 10 segments 17.2 -> 13.1 us,
+//   15 segments 22.3 -> 24.7, 20 segments 20.1 -> 24.1 with six k steps in registers: 204 VGPRs, two workgroups per CU)
+// ------------------------------------------------------------------------------------
+#ifdef MSNAP_TOOLS_TIMELINE
+// phase timestamps (s_memrealtime, 100 MHz) of the fused kernel: tools/grid_sample_timeline.py
+__device__ unsigned long long g_gs_timeline[1024 * 8];
+// (stamps go to LDS and leave at the end: a global store per stamp would sit in every later s_waitcnt vmcnt(0))
+#define MSNAP_GSTL(k)                                              \
+  do {                                                             \
+    if (threadIdx.x == 0) s_gs_tl[(k)] = wall_clock64();           \
+  } while (0)
+#define MSNAP_GSTL_FLUSH()                                                                   \
+  do {                                                                                       \
+    lds_barrier();                                                                           \
+    if (threadIdx.x < 8 && blockIdx.x < 1024) g_gs_timeline[blockIdx.x * 8 + threadIdx.x] = s_gs_tl[threadIdx.x]; \
+  } while (0)
+}  // namespace msnap
+extern "C" int msnap_debug_read_gs_timeline(unsigned long long *out, int n_words) {
+  if (hipDeviceSynchronize() != hipSuccess) return MSNAP_EHIP;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(msnap::g_gs_timeline), (size_t)n_words * 8) == hipSuccess ? MSNAP_OK : MSNAP_EHIP;
+}
+namespace msnap {
+#else
+#define MSNAP_GSTL(k) do { } while (0)
+#define MSNAP_GSTL_FLUSH() do { } while (0)
+#endif
+
+typedef double v4f64s __attribute__((ext_vector_type(4)));
+constexpr int kFuseKS = 3;
+constexpr int kFuseTasks = 4;
+
+template <int NC>
+__global__ void __launch_bounds__(256, 2)
+grid_sample_kernel(const double *__restrict__ wp, const double *__restrict__ frag, int ks_pitch,
+                   const double *__restrict__ gdur, const int32_t *__restrict__ gstatus, double dt, int N, int M, int S,
+                   int DW, double *__restrict__ coef, double *__restrict__ dur, int32_t *__restrict__ status,
+                   double *__restrict__ pos, double *__restrict__ pos_t, int Rp, double *__restrict__ kbox,
+                   unsigned *__restrict__ kkey) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int m = M + 1, ncols = M * NC, nct = (ncols + 15) >> 4, nks = (m + 3) >> 2;
+  const int nrt = (DW * 4 + 15) >> 4, rows16 = nrt * 16, ntasks = nrt * nct;
+  const int wpitch = m | 1, cpitch = ncols + 2;
+  // t / nrt for t < 16, nrt <= 4, and e / (4 m) for e < 512, as multiplications (a dozen integer divisions by kernel
+  // arguments were 490 scalar instructions in front of the first load)
+  const int nrt_inv = nrt == 3 ? 86 : 256 >> (nrt >> 1);
+  const unsigned m4_inv = (1u << 20) / (unsigned)(m * 4) + 1u;
+  double *sB = smem;                                        // [M + 1] running sums of the grid's durations
+  double *sW = sB + ((m + 1) & ~1);                         // [rows16][wpitch] waypoints, row = 4 * drone + axis
+  double *sC = sW + (((size_t)rows16 * wpitch + 1) & ~(size_t)1);   // [DW * 4][cpitch] coefficients
+  double *sImg = sC + (size_t)DW * 4 * cpitch;              // [DW][S][3]
+  int *sBad = reinterpret_cast<int *>(sImg + (size_t)DW * S * 3);   // [DW] non-finite waypoints; [DW]: generic search
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform: the task tests become scalar branches)
+  const int col = lane & 15, kq = lane >> 4;
+  const int grid_st = gstatus[0];
+  const size_t per_drone = (size_t)S * 3;
+#ifdef MSNAP_TOOLS_TIMELINE
+  __shared__ unsigned long long s_gs_tl[8];
+#endif
+  MSNAP_GSTL(0);
+
+  if (tid == 0) {
+    double acc = 0.0;
+    bool ranges = dt > 0.0;
+    sB[0] = 0.0;
+    for (int i = 0; i < M; ++i) {
+      const double Ti = gdur[i];
+      ranges = ranges && (Ti >= 0.0);
+      acc = acc + Ti;
+      sB[i + 1] = acc;
+    }
+    sBad[DW] = ranges ? 0 : 1;
+  }
+  for (int e = tid; e < rows16 * wpitch; e += blockDim.x) sW[e] = 0.0;
+
+  for (int d0 = blockIdx.x * DW; d0 < N; d0 += gridDim.x * DW) {
+    const int nd = N - d0 < DW ? N - d0 : DW;
+    const int words = nd * m * 4;                       // <= 512: two per thread
+    const double *wsrc = wp + (size_t)d0 * m * 4;
+    const int e0 = tid, e1 = tid + 256;
+    const double w0 = wsrc[e0 < words ? e0 : 0], w1 = wsrc[e1 < words ? e1 : 0];
+    // the operator fragments of this wave's tasks, in the same flight (loaded per pass over d0, so that they are not
+    // live through the sampling loops: nearly every workgroup makes one pass)
+    double bq[kFuseTasks][kFuseKS];
+#pragma unroll
+    for (int ti = 0; ti < kFuseTasks; ++ti) {
+      // (a wave without a ti-th task repeats the last one: no branches around the loads and the MFMAs, one around
+      // the write)
+      const int t = wave + 4 * ti < ntasks ? wave + 4 * ti : ntasks - 1;
+      const double *bsrc = frag + (size_t)((t * nrt_inv) >> 8) * ks_pitch * kWave + lane;
+#pragma unroll
+      for (int ks = 0; ks < kFuseKS; ++ks) bq[ti][ks] = bsrc[(ks < nks ? ks : 0) * kWave];
+    }
+    if (tid < DW) sBad[tid] = 0;
+    lds_barrier();
+    MSNAP_GSTL(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = h ? e1 : e0;
+      const double w = h ? w1 : w0;
+      if (e < words) {
+        const int dl = (int)(((unsigned)e * m4_inv) >> 20), r = e - dl * (m * 4);
+        sW[(size_t)(dl * 4 + (r & 3)) * wpitch + (r >> 2)] = w;
+        if (!__builtin_isfinite(w)) sBad[dl] = 1;
+      }
+    }
+    lds_barrier();
+    MSNAP_GSTL(2);
+    // the GEMM: C[row][c] = sum_j W[row][j] Gop[j][c], k ascending as in grid_gemm_kernel.  All A operands first (one
+    // LDS flight), then the tasks' MFMA chains side by side, then the results (written as they are: a drone with a
+    // non-finite waypoint is turned into NaN by the readers below)
+    {
+      double av[kFuseTasks][kFuseKS];
+#pragma unroll
+      for (int ti = 0; ti < kFuseTasks; ++ti) {
+        const int t = wave + 4 * ti < ntasks ? wave + 4 * ti : ntasks - 1;
+        const double *arow = sW + (size_t)((t - ((t * nrt_inv) >> 8) * nrt) * 16 + col) * wpitch;
+#pragma unroll
+        for (int ks = 0; ks < kFuseKS; ++ks) {
+          const int j = 4 * ks + kq;
+          const double v = arow[j < m ? j : m - 1];
+          av[ti][ks] = j < m ? v : 0.0;
+        }
+      }
+      v4f64s acc[kFuseTasks];
+#pragma unroll
+      for (int ti = 0; ti < kFuseTasks; ++ti) acc[ti] = v4f64s{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < kFuseKS; ++ks)
+        if (ks < nks) {
+#pragma unroll
+          for (int ti = 0; ti < kFuseTasks; ++ti)
+            acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti][ks], bq[ti][ks], acc[ti], 0, 0, 0);
+        }
+#pragma unroll
+      for (int ti = 0; ti < kFuseTasks; ++ti) {
+        const int t = wave + 4 * ti;
+        const int ct = (t * nrt_inv) >> 8, rt = t - ct * nrt;
+        const int c = 16 * ct + col;
+        if (t < ntasks && c < ncols) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int dl = rt * 4 + r;                  // row 4 * dl + kq: drone dl, axis kq
+            if (dl < DW) sC[(size_t)(dl * 4 + kq) * cpitch + c] = acc[ti][r];
+          }
+        }
+      }
+    }
+    MSNAP_GSTL(7);
+    lds_barrier();
+    MSNAP_GSTL(3);
+    // coefficients, durations and status as msnap_solve_grid leaves them: a wave per drone, 16 bytes per lane
+    {
+      const int ppd = M * 4 * NC / 2;                     // double2 per drone
+      for (int dl = wave; dl < nd; dl += 4) {
+        const bool bad = grid_st != 0 || sBad[dl] != 0;
+        double *cout = coef + (size_t)(d0 + dl) * M * 4 * NC;
+        for (int e = lane; e < ppd; e += kWave) {
+          const int g = 2 * e;
+          const int kc = g % NC, q = g / NC;
+          const int a = q & 3, seg = q >> 2;
+          double2 v = *reinterpret_cast<const double2 *>(sC + (size_t)(dl * 4 + a) * cpitch + seg * NC + kc);
+          if (bad) v = make_double2(__builtin_nan(""), __builtin_nan(""));
+          *reinterpret_cast<double2 *>(cout + g) = v;
+        }
+      }
+      for (int e = tid; e < nd * M; e += blockDim.x) dur[(size_t)d0 * M + e] = gdur[e % M];
+      if (tid < nd) status[d0 + tid] = sBad[tid] ? MSNAP_ST_NONFINITE : grid_st;
+    }
+    MSNAP_GSTL(4);
+    const int items = nd * M * 3;
+    const bool generic = sBad[DW] != 0;
+    for (int it = tid; it < items; it += blockDim.x) {
+      const int a = it % 3;
+      const int i = (it / 3) % M;
+      const int dl = it / (3 * M);
+      double *img = sImg + (size_t)dl * per_drone;
+      const double *cbase = sC + (size_t)dl * 4 * cpitch;
+      const bool bad = grid_st != 0 || sBad[dl] != 0;
+      if (generic || bad) {
+        // (a NaN row evaluates to NaN at every sample, whichever piece the search picks)
+        if (i == 0)
+          for (int sq = 0; sq < S; ++sq) {
+            double x = __builtin_nan("");
+            if (!bad) sample_point_generic<NC>(cbase, gdur, M, (double)sq * dt, a, x, NC, cpitch);
+            img[(size_t)sq * 3 + a] = x;
+          }
+        continue;
+      }
+      const double *crow = cbase + (size_t)a * cpitch + i * NC;
+      sample_piece<NC>(sB[i], sB[i + 1], i, M, S, dt, img, 3, a, [&](double (&c)[NC]) {
+#pragma unroll
+        for (int q = 0; q < NC; q += 2) {
+          const double2 v = *reinterpret_cast<const double2 *>(crow + q);
+          c[q] = v.x;
+          c[q + 1] = v.y;
+        }
+      });
+    }
+    lds_barrier();
+    MSNAP_GSTL(5);
+    sample_image_out(sImg, tid, blockDim.x, nd, d0, per_drone, S, pos, pos_t, Rp, kbox, kkey);
+    lds_barrier();
+    MSNAP_GSTL(6);
+  }
+  MSNAP_GSTL_FLUSH();
 }
 
 __global__ void collide_key_kernel(const double *__restrict__ pos, int N, int S, double *__restrict__ box,
@@ -416,6 +652,51 @@ int launch_sample(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, c
                          ctx->stream, (const double *)pos, n_drones, n_samples, kbox, kkey);
     }
   }
+  MSNAP_HIP(ctx, hipGetLastError());
+  return MSNAP_OK;
+}
+
+// The fused launch, or the two kernels when the shape is outside its range (more than 11 segments, samples beyond the
+// LDS image).  `pos_t` / `keys_form` as launch_sample.
+int launch_grid_sample(msnap_ctx *ctx, int n_drones, const double *wp, double dt, int n_samples, double *coef,
+                       double *dur, int32_t *status, double *pos, double *pos_t, bool keys_form) {
+  const int M = ctx->grid_seg, m = M + 1, nc = ctx->order + 1;
+  const int ks_pitch = grid_frag_ks_pitch(ctx, M);
+  const size_t img_per_drone = (size_t)n_samples * 3 * sizeof(double);
+  const int ncols = M * nc, nct = (ncols + 15) / 16, nks = (m + 3) / 4;
+  int dw = 256 / (M * 3);
+  if (dw > 16) dw = 16;
+  auto lds_of = [&](int d) -> size_t {
+    const size_t rows16 = (size_t)((d * 4 + 15) / 16) * 16;
+    return (size_t)(((m + 1) & ~1) + ((rows16 * (m | 1) + 1) & ~(size_t)1) + (size_t)d * 4 * (ncols + 2)) * 8 +
+           d * img_per_drone + (size_t)(d + 2) * 4;
+  };
+  while (dw > 1 && (dw * img_per_drone > 48 * 1024 || lds_of(dw) > 64 * 1024 ||
+                    ((dw * 4 + 15) / 16) * nct > 4 * kFuseTasks))
+    --dw;
+  const bool fused = !ctx->no_grid_sample && ks_pitch > 0 && nks <= kFuseKS && dw >= 1 && lds_of(dw) <= 64 * 1024 &&
+                     ((dw * 4 + 15) / 16) * nct <= 4 * kFuseTasks && dw * (size_t)m * 4 <= 512;
+  if (!fused) {
+    int rc = launch_solve_grid(ctx, n_drones, wp, coef, dur, status);
+    if (rc) return rc;
+    return launch_sample(ctx, n_drones, M, coef, dur, dt, n_samples, 3, pos, pos_t, keys_form);
+  }
+  if (stream_is_capturing(ctx))
+    for (DevBuf *b : {&ctx->grid_t, &ctx->grid_frag, &ctx->grid_dur, &ctx->grid_status}) b->in_graph = true;
+  const int Rp = (n_drones + kRowBlockRows - 1) / kRowBlockRows * kRowBlockRows;
+  double *kbox = keys_form ? pos_t : nullptr;
+  unsigned *kkey = keys_form ? reinterpret_cast<unsigned *>(pos_t + (size_t)n_drones * 6) : nullptr;
+  if (keys_form) pos_t = nullptr;
+  size_t blocks = ((size_t)n_drones + dw - 1) / dw;
+  if (blocks > (size_t)ctx->n_cu * 64) blocks = (size_t)ctx->n_cu * 64;
+  note_kernel(ctx, "msnap::grid_sample_kernel<%d>", nc);
+#define MSNAP_GS_LAUNCH(NCV)                                                                                            \
+  hipLaunchKernelGGL((grid_sample_kernel<NCV>), dim3((unsigned)blocks), dim3(256), lds_of(dw), ctx->stream, wp,          \
+                     (const double *)ctx->grid_frag.p, ks_pitch, (const double *)ctx->grid_dur.p,                         \
+                     (const int32_t *)ctx->grid_status.p, dt, n_drones, M, n_samples, dw, coef, dur, status, pos, pos_t,  \
+                     Rp, kbox, kkey)
+  if (nc == 8) MSNAP_GS_LAUNCH(8); else MSNAP_GS_LAUNCH(10);
+#undef MSNAP_GS_LAUNCH
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;
 }
@@ -1442,10 +1723,7 @@ collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, const int32
 #pragma unroll
   for (int c = 0; c < kChunks; ++c) {
     const unsigned long long m = __ballot(pl[c] > 0);      // (0 behind the group's own row)
-    if (pl[c] > 0) {
-      sIt[nB + __popcll(m & ((1ull << lane) - 1ull))] = pl[c] - 1;
-      cg.blist[(size_t)gq * cg.nG + c * kWave + lane] = 0;      // the row is left clean for the next pass
-    }
+    if (pl[c] > 0) sIt[nB + __popcll(m & ((1ull << lane) - 1ull))] = pl[c] - 1;
     nB += __popcll(m);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -1491,6 +1769,11 @@ collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, const int32
     partner[out] = bj;
     hit[out] = (dist < 2.0 * radius) ? 1 : 0;
   }
+  // the row is left clean for the next pass (here, not where it is read: the counter the candidate loads wait on
+  // counts stores too, and they would wait for these)
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c)
+    if (pl[c] > 0) cg.blist[(size_t)gq * cg.nG + c * kWave + lane] = 0;
 }
 
 // The evaluator of the surviving group pairs: a fixed grid of waves walks the list, one item per wave slot at the
@@ -1971,7 +2254,7 @@ collide_rank_kernel(const unsigned *__restrict__ key, int N, int32_t *__restrict
       if (q < nq) c += __popcll(__ballot(mine[q] < ki));
     if (lane == 0) cnt[w][t] = c;
   }
-  __syncthreads();
+  lds_barrier();      // (the zeroing stores above need not have landed)
   if (threadIdx.x < kRankTile && i0 + (int)threadIdx.x < N) {
     int r = 0;
 #pragma unroll
@@ -2062,7 +2345,7 @@ collide_gather_kernel(const double *__restrict__ pos, int N, int Rp, int E, doub
       if (i < kTileRows && tx < ne && r0 + i < N) psorted[(size_t)(r0 + i) * E + e0 + tx] = val[u];
     }
   }
-  __syncthreads();
+  lds_barrier();      // (not __syncthreads(): that would sit out the round trip of the stores above)
   {
     const int tx = tid & 63, ty = tid >> 6;
     for (int i = ty; i < ne; i += 4) prow_t[(size_t)(e0 + i) * Rp + r0 + tx] = tile[tx * kTilePitch + i];
@@ -2078,7 +2361,7 @@ collide_gather_kernel(const double *__restrict__ pos, int N, int Rp, int E, doub
     }
     sF[k - 1][row] = r0 + row + k < N ? f : INFINITY;      // (rows past the end replay row N - 1)
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < kTileRows + kTileHalo) {
     // row t of the tile (the halo rows too): its pairs with the rows after it and before it
     double b = INFINITY;

@@ -318,6 +318,11 @@ bool grid_gemm_supported(const msnap_ctx *ctx, int n_seg) {
   return (n_seg + 1 + 3) / 4 <= kStreamMaxKS;
 }
 
+int grid_frag_ks_pitch(const msnap_ctx *ctx, int n_seg) {
+  if (!grid_gemm_supported(ctx, n_seg)) return 0;
+  return grid_gemm_reg_supported(ctx, n_seg) ? kGridMaxKS : (n_seg + 1 + 3) / 4;
+}
+
 int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_device) {
   const int m = n_seg + 1;
   const int nc = ctx->order + 1;
@@ -355,15 +360,17 @@ int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_dev
 
 // Launch geometry of the streaming variant.  Large batches: RT = 4 row tiles (16 drones) per wave,
 // every wave walks all column tiles, persistent over the row groups.  Small batches: one row tile
-// per wave and the column tiles sliced over blockIdx.y until the chip has ~4 waves per CU.
+// per wave and the column tiles sliced over blockIdx.y until the chip has ~16 waves per CU.
 template <int NC, int NKS>
 static void launch_stream_nks(msnap_ctx *ctx, int N, int M, const double *wp, double *coef, double *dur,
                               int32_t *status) {
   const int nct = (M * NC + 15) / 16;
-  const int target = ctx->n_cu * 4;
+  // (16 waves per CU: 4096 drones x 20 segments 9.7 -> 8.1 us against 4, 8192 drones 13.3 -> 12.0; one row group
+  // and the reference's 2 x 49 shape are sliced down to single column tiles either way)
+  const int target = ctx->n_cu * (ctx->gemm_stream_waves_per_cu > 0 ? ctx->gemm_stream_waves_per_cu : 16);
   const double *frag = (const double *)ctx->grid_frag.p, *gdur = (const double *)ctx->grid_dur.p;
   const int32_t *gst = (const int32_t *)ctx->grid_status.p;
-  if (N >= 16 * target) {
+  if (N >= 16 * ctx->n_cu * 4) {
     constexpr int RT = 4;
     const int nrg = (N + 4 * RT - 1) / (4 * RT);
     int grid = ctx->n_cu * 16;

@@ -41,6 +41,11 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() is a release / acquire fence pair around s_barrier, and the
+// release waits for every global store the wave has in flight (s_waitcnt vmcnt(0)): a kernel that has just issued
+// stores would sit out their round trip at the next barrier although nothing in the workgroup reads them back.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // growable device buffer
 struct DevBuf {
   void *p = nullptr;
@@ -83,6 +88,8 @@ struct msnap_ctx {
   // launch-geometry options (msnap_set_option; the MSNAP_* environment variables of msnap.h only
   // seed them in msnap_create -- nothing on a launch path reads the environment)
   int no_twist = 0;             // "no_twist": keep small batches on the one-sided kernels (A/B timing)
+  int gemm_stream_waves_per_cu = 0;   // "gemm_stream_waves_per_cu": wave target of the streaming GEMM's column slicing (0: default)
+  int no_grid_sample = 0;      // "no_grid_sample": msnap_solve_grid_sample runs the two kernels (A/B timing)
   int no_twin = 0;             // "no_twin": batches keep solve_kernel_reg where solve_kernel_twin would run (A/B timing)
   int twin_max_drones = 0;      // "twin_max_drones": largest batch that takes solve_kernel_twin (0: default per order)
   int twist_max_drones = 0;     // "twist_max_drones": batches up to this size take the small-batch kernel (0: default)
@@ -172,5 +179,9 @@ int launch_grid_prepare(msnap_ctx *ctx, int n_seg, const double *t, int t_on_dev
 int launch_solve_grid(msnap_ctx *ctx, int n_drones, const double *wp, double *coef, double *dur,
                       int32_t *status);
 bool grid_gemm_supported(const msnap_ctx *ctx, int n_seg);
+// k-step pitch of the packed operator fragments ([column tile][pitch][64]); 0: no GEMM operator for this grid
+int grid_frag_ks_pitch(const msnap_ctx *ctx, int n_seg);
+int launch_grid_sample(msnap_ctx *ctx, int n_drones, const double *wp, double dt, int n_samples, double *coef,
+                       double *dur, int32_t *status, double *pos, double *pos_t, bool keys_form);
 
 }  // namespace msnap

@@ -117,6 +117,26 @@ class DeviceCompute:
             self.ctx.sample_collide_device(n, M, coef, dur, dt, n_samples, pos, pos_t)
         return pos, pos_t
 
+    def solve_grid_sample(self, wp, dt, n_samples, n_cols=None):
+        """solve_grid and the sampler as one launch (msnap_solve_grid_sample_device): (coef, dur, status, pos, pos_t),
+        the same tensors, bit for bit, as `solve_grid` followed by `sample_rows_t` (pos_t is None where that would
+        return None, or when `n_cols` is None and no hand-over is wanted)."""
+        torch = self.torch
+        n, m, _ = wp.shape
+        M = m - 1
+        if wp.dim() != 3 or wp.shape[2] != 4 or m != self.ctx.grid_waypoints():
+            raise ValueError(f"solve_grid_sample: wp must be [n, {self.ctx.grid_waypoints()}, 4] for the prepared grid, got {tuple(wp.shape)}")
+        coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
+        dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
+        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
+        pos_t = None
+        if n_cols is not None and self.ctx.collide_reads_rows_t(n, 0, n_cols, n_samples):
+            pos_t = torch.empty((self.ctx.collide_rows_t_doubles(n, n_samples),), dtype=torch.float64, device=self.device)
+        if n:
+            self.ctx.solve_grid_sample_device(n, M, wp, dt, n_samples, coef, dur, status, pos, pos_t)
+        return coef, dur, status, pos, pos_t
+
     def collide(self, pos_rows, row_offset, pos_all, radius, rows_t=None):
         torch = self.torch
         r = pos_rows.shape[0]

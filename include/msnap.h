@@ -291,6 +291,16 @@ size_t msnap_collide_rows_t_doubles(int n_rows, int n_samples);
 int msnap_formation_collide_reads_rows_t(const msnap_ctx *ctx, int n_rows, int row_offset, int n_cols, int n_samples);
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef,
                                 const double *dur, double dt, int n_samples, double *pos, double *pos_t);
+/* The shared-grid solve and the sampler as ONE launch, the reference's drones_pols_generator -> drones_traj_generator
+ * step for a swarm on a common grid (scripts/drones_pols_generator.py:44-77 -> scripts/drones_traj_generator.py:28-46):
+ * the same outputs, bit for bit, as msnap_solve_grid_device followed by msnap_sample_collide_device (pos_t != NULL) or
+ * msnap_sample_device with 3 axes (pos_t == NULL) -- the coefficients stay in LDS between the fp64 MFMA product and
+ * the Horner loops, which saves the dependent launch and the read-back.  Shapes outside the fused kernel's range
+ * (more than 11 segments, where it stops paying; samples beyond its LDS image) run as those two launches; the option "no_grid_sample"
+ * forces that (A/B timing).  n_samples == 0: the solve alone. */
+int msnap_solve_grid_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *wp, double dt, int n_samples,
+                                   double *coef, double *dur, int32_t *status, double *pos /* [n_drones][n_samples][3] */,
+                                   double *pos_t /* NULL or msnap_collide_rows_t_doubles(n_drones, n_samples) doubles */);
 int msnap_formation_collide_t_device(msnap_ctx *ctx, int n_rows, int row_offset, int n_cols,
                                      int n_samples, const double *pos_rows_t, const double *pos_rows,
                                      const double *pos_cols, double radius, double *min_dist,

@@ -79,6 +79,7 @@ int main(void) {
   EXPECT(msnap_collide_rows_t_doubles(0, 5) == 0 && msnap_collide_rows_t_doubles(1, 2) == 128 * 2 * 3);
   EXPECT(msnap_collide_rows_t_doubles(4096, 91) == (size_t)4096 * 91 * 3 && msnap_collide_rows_t_doubles(129, 1) == 256 * 3);
   EXPECT(msnap_sample_collide_device(NULL, 1, 1, d, d, 0.1, 2, d, d) == MSNAP_EINVAL);
+  EXPECT(msnap_solve_grid_sample_device(NULL, 1, 1, d, 0.1, 2, d, d, NULL, d, d) == MSNAP_EINVAL);
   EXPECT(msnap_formation_collide_t_device(NULL, 1, 0, 1, 2, d, d, d, 0.1, d, i, i) == MSNAP_EINVAL);
   EXPECT(msnap_formation_part_bytes(0) == 0 && msnap_formation_part_bytes(-3) == 0);
   EXPECT(msnap_formation_part_bytes(1) == 16 && msnap_formation_part_bytes(2) == 24 && msnap_formation_part_bytes(4096) == 49152);

@@ -29,6 +29,7 @@ int solve_kernel_setup(msnap_ctx *) { return unreachable(); }
 bool solve_uses_global_scratch(const msnap_ctx *, int) { return unreachable() != 0; }
 int launch_grid_prepare(msnap_ctx *, int, const double *, int) { return unreachable(); }
 int launch_solve_grid(msnap_ctx *, int, const double *, double *, double *, int32_t *) { return unreachable(); }
+int launch_grid_sample(msnap_ctx *, int, const double *, double, int, double *, double *, int32_t *, double *, double *, bool) { return unreachable(); }
 bool grid_gemm_supported(const msnap_ctx *, int) { return unreachable() != 0; }
 
 }  // namespace msnap

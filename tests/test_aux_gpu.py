@@ -686,3 +686,67 @@ def test_mesh_sweep_with_partially_nonfinite_paths(ctx7):
     np.testing.assert_allclose(md, rmd, rtol=0, atol=1e-12)
     np.testing.assert_array_equal(hit, rhit)
     assert np.isinf(md[4]) and not hit[4] and hit.any()
+
+
+@pytest.mark.parametrize("order,n,m,S,fused", [(7, 4096, 10, 91, 1), (7, 4096, 20, 96, 0), (7, 257, 5, 33, 1),
+                                               (9, 100, 11, 40, 1), (7, 37, 12, 50, 0), (7, 64, 24, 30, 0),
+                                               (9, 1000, 10, 91, 1), (7, 5, 1, 7, 1), (9, 333, 7, 64, 1),
+                                               (7, 130, 8, 700, 1), (7, 40, 6, 2700, 0), (7, 3100, 3, 20, 1),
+                                               (7, 4099, 9, 91, 1), (9, 3333, 11, 91, 1)])
+def test_solve_and_sampler_in_one_launch(order, n, m, S, fused):
+    """msnap_solve_grid_sample_device: coefficients, durations, status, positions and the hand-over buffer are those of
+    msnap_solve_grid_device followed by the sampler, bit for bit -- through the fused kernel where it applies (the
+    kernel name says which ran) and through the two launches beyond its range (12 and more segments, 2700 samples); a drone with
+    a non-finite waypoint gets its status and NaN outputs exactly as there."""
+    import torch
+    from drone_path_planning_python_amd import Context, swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    ctx = Context(order=order)
+    try:
+        wp, _ = swarm(900 + n, n, m)
+        wp[..., :3] *= 0.3
+        if n > 4:
+            wp[3, m // 2, 1] = np.nan
+            wp[n - 1, 0, 3] = np.inf
+        t = np.linspace(0.0, 10.0, m + 1)
+        ctx.prepare_grid(t)
+        comp = sw.DeviceCompute(ctx, torch)
+        d_wp = torch.from_numpy(wp).cuda()
+        for n_cols in (None, n):
+            c0, d0, s0 = comp.solve_grid(d_wp)
+            if n_cols is None:
+                p0, t0 = comp.sample(c0, d0, 0.1, S), None
+            else:
+                p0, t0 = comp.sample_rows_t(c0, d0, 0.1, S, n_cols=n_cols)
+            c1, d1, s1, p1, t1 = comp.solve_grid_sample(d_wp, 0.1, S, n_cols=n_cols)
+            assert ctx.last_kernel().startswith("msnap::grid_sample_kernel") == bool(fused), ctx.last_kernel()
+            for a, b in ((c0, c1), (d0, d1), (s0, s1), (p0, p1)):
+                np.testing.assert_array_equal(a.cpu().numpy().view(np.uint8), b.cpu().numpy().view(np.uint8))
+            assert (t0 is None) == (t1 is None)
+            if t0 is not None:
+                keys = ctx.collide_takes_broad_phase(n, 0, n, S)
+                used = n * 6 * 8 + n * 4 if keys else None      # boxes + keys; the row image's padding rows are not written
+                a, b = t0.cpu().numpy().view(np.uint8), t1.cpu().numpy().view(np.uint8)
+                if keys:
+                    np.testing.assert_array_equal(a[:used], b[:used])
+                else:
+                    pitch = (n + 127) // 128 * 128
+                    np.testing.assert_array_equal(t0.cpu().numpy().reshape(S, 3, pitch)[:, :, :n],
+                                                  t1.cpu().numpy().reshape(S, 3, pitch)[:, :, :n])
+                # and the pairwise pass accepts either hand-over
+                r0 = comp.collide(p0, 0, p0, 0.2, rows_t=t0)
+                r1 = comp.collide(p1, 0, p1, 0.2, rows_t=t1)
+                for x, y in zip(r0, r1):
+                    np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+        if n > 4:
+            st = s1.cpu().numpy()
+            assert st[3] != 0 and st[n - 1] != 0 and np.count_nonzero(st) == 2
+            assert np.isnan(p1[3].cpu().numpy()).all() and np.isfinite(p1[2].cpu().numpy()).all()
+        # the A/B switch runs the two kernels
+        ctx.set_option("no_grid_sample", 1)
+        c2, d2, s2, p2, _ = comp.solve_grid_sample(d_wp, 0.1, S)
+        assert not ctx.last_kernel().startswith("msnap::grid_sample_kernel")
+        np.testing.assert_array_equal(p2.cpu().numpy().view(np.uint8), p1.cpu().numpy().view(np.uint8))
+        torch.cuda.synchronize()
+    finally:
+        ctx.close()

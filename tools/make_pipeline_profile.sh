@@ -42,8 +42,8 @@ with open(out + "/pipeline_summary.md", "w") as f:
     for fn in glob.glob(f"{out}/pmc3/**/*counter_collection.csv", recursive=True) + glob.glob(f"{out}/pmc3all/**/*counter_collection.csv", recursive=True):
         allp = "/pmc3all/" in fn
         for r in csv.DictReader(open(fn)):
-            for k in (("collide_span_kernel",) if allp else ("mesh_sweep_kernel", "collide_eval_groups_kernel", "collide_gather_kernel", "sample_kernel")):
-                if k in r["Kernel_Name"]:
+            for k in (("collide_span_kernel",) if allp else ("mesh_sweep_kernel", "collide_eval_groups_kernel", "collide_gather_kernel", "sample_kernel", "grid_sample_kernel")):
+                if "::" + k in r["Kernel_Name"]:
                     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     counters = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
     counters["csrc_sha"] = csrc_sha()      # bench.py quotes these counters only for the sources they were taken from
