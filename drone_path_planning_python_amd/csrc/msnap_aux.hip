@@ -232,7 +232,7 @@ sample_generic_kernel(const double *__restrict__ coef, const double *__restrict_
 // A workgroup owns DW whole drones; results go through an LDS image of their [S][naxes] blocks and
 // leave as 16-byte-per-lane runs (direct 8-byte stores at a 24-byte stride reach L2 as 21-byte requests).
 // the samples of one (drone, piece, axis): s_lo .. s_hi - 1 from the running sums, Horner on the piece's row (`load`
-// fills it once the range is known to be non-empty)
+// fills it)
 template <int NC, class Load>
 __device__ __forceinline__ void sample_piece(double bi, double bn, int i, int M, int S, double dt, double *img,
                                              int naxes, int a, Load load) {
@@ -245,11 +245,12 @@ __device__ __forceinline__ void sample_piece(double bi, double bn, int i, int M,
     while (c < S && (double)c * dt < b) ++c;
     return c;
   };
-  const int s_lo = (i == 0) ? 0 : first_at(bi);
-  const int s_hi = (i == M - 1) ? S : first_at(bn);
-  if (s_lo >= s_hi) return;
+  // (the row is fetched before the ranges are worked out -- two fp64 divisions and their corrections -- so that its
+  // latency runs under them; a piece without samples fetches it for nothing)
   double c[NC];
   load(c);
+  const int s_lo = (i == 0) ? 0 : first_at(bi);
+  const int s_hi = (i == M - 1) ? S : first_at(bn);
   for (int sq = s_lo; sq < s_hi; ++sq) {
     const double tl = (double)sq * dt - bi;
     double x = 0.0;
@@ -324,6 +325,11 @@ __device__ __forceinline__ void sample_image_out(const double *sImg, int tid, in
   }
 }
 
+// x / d for 32-bit x through one v_mul_hi_u32: magic = floor((2^32 - 1) / d) + 1 is exact while x * d < 2^32 (items and
+// their divisors here are a few thousand at most); d == 1 has no 32-bit magic and is passed as 0
+__device__ __forceinline__ unsigned div_magic(unsigned d) { return d > 1 ? 0xffffffffu / d + 1u : 0u; }
+__device__ __forceinline__ int div_by(int x, unsigned magic) { return magic ? (int)__umulhi((unsigned)x, magic) : x; }
+
 template <int NC>
 __global__ void __launch_bounds__(256)
 sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, double dt, int N, int M, int S,
@@ -336,6 +342,7 @@ sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, d
   double *sImg = reinterpret_cast<double *>(sGen + ((DW + 1) & ~1));  // [DW][S][naxes]
   const int tid = threadIdx.x;
   const size_t per_drone = (size_t)S * naxes;
+  const unsigned inv_piece = div_magic((unsigned)(naxes * M)), inv_axes = div_magic((unsigned)naxes);
   for (int d0 = blockIdx.x * DW; d0 < N; d0 += gridDim.x * DW) {
     const int nd = N - d0 < DW ? N - d0 : DW;
     if (tid < nd) {
@@ -354,9 +361,8 @@ sample_kernel(const double *__restrict__ coef, const double *__restrict__ dur, d
     __syncthreads();
     const int items = nd * M * naxes;
     for (int it = tid; it < items; it += blockDim.x) {
-      const int a = it % naxes;
-      const int i = (it / naxes) % M;
-      const int dl = it / (naxes * M);
+      const int dl = div_by(it, inv_piece), rem = it - dl * (naxes * M);
+      const int i = div_by(rem, inv_axes), a = rem - i * naxes;
       const double *cbase = coef + (size_t)(d0 + dl) * M * 4 * NC;
       double *img = sImg + (size_t)dl * per_drone;
       if (sGen[dl]) {
@@ -436,6 +442,7 @@ grid_sample_kernel(const double *__restrict__ wp, const double *__restrict__ fra
   // arguments were 490 scalar instructions in front of the first load)
   const int nrt_inv = nrt == 3 ? 86 : 256 >> (nrt >> 1);
   const unsigned m4_inv = (1u << 20) / (unsigned)(m * 4) + 1u;
+  const unsigned inv_piece = div_magic((unsigned)(3 * M));
   double *sB = smem;                                        // [M + 1] running sums of the grid's durations
   double *sW = sB + ((m + 1) & ~1);                         // [rows16][wpitch] waypoints, row = 4 * drone + axis
   double *sC = sW + (((size_t)rows16 * wpitch + 1) & ~(size_t)1);   // [DW * 4][cpitch] coefficients
@@ -563,9 +570,8 @@ grid_sample_kernel(const double *__restrict__ wp, const double *__restrict__ fra
     const int items = nd * M * 3;
     const bool generic = sBad[DW] != 0;
     for (int it = tid; it < items; it += blockDim.x) {
-      const int a = it % 3;
-      const int i = (it / 3) % M;
-      const int dl = it / (3 * M);
+      const int dl = div_by(it, inv_piece), rem = it - dl * (3 * M);
+      const int i = rem / 3, a = rem - i * 3;
       double *img = sImg + (size_t)dl * per_drone;
       const double *cbase = sC + (size_t)dl * 4 * cpitch;
       const bool bad = grid_st != 0 || sBad[dl] != 0;
