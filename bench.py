@@ -398,7 +398,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                                 ).to(device)
         from drone_path_planning_python_amd import Context
         side_ctx = Context(ctx.device_id, 7, 16)      # the mesh sweep's own stream (swarm.DeviceCompute)
-    comp = swarm.DeviceCompute(ctx, torch, side_ctx=side_ctx)
+    # (output tensors allocated once and reused by every pipeline: a pass's results are consumed before the next starts)
+    comp = swarm.DeviceCompute(ctx, torch, side_ctx=side_ctx, reuse_outputs=True)
     twp = torch.from_numpy(np.ascontiguousarray(wp[lo:hi])).to(device)
     tt = torch.from_numpy(t).to(device)
     # several ranks: "parts" (every pair on exactly one rank, second all-gather, fold) or "whole" (every rank the whole
@@ -464,6 +465,8 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
             comp.mesh_abort()       # joins the side stream if something above raised between begin and end
         return status, hit, mh, md, pos
 
+    host = {"enqueue_s": 0.0}
+
     def timed(overlap, recs, fused=False):
         for _ in range(warm):
             one(None, overlap, fused)
@@ -474,6 +477,7 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
         t0 = time.perf_counter()
         for r in range(reps):
             out = one(recs[r] if recs else None, overlap, fused)
+        host["enqueue_s"] = time.perf_counter() - t0      # the host's share: the loop without the final drain
         torch.cuda.synchronize()
         w = time.perf_counter() - t0
         if use_pg:
@@ -499,20 +503,41 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     wall_serial = wall
     stage_out = [x.clone() for x in (status, hit, md, pos_keep)]
     wall, (status, hit, mh, md, pos_keep) = timed(tris is not None, None, fused=True)
+    host_us = host["enqueue_s"] / reps * 1e6
     fused_kernel = None
     # the fused launch on its own (and that it gives the separate stages' results bit for bit)
     for a, b in zip(stage_out, (status, hit, md, pos_keep)):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), "fused solve + sampler differs from the two stages"
-    for _ in range(3):
-        comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
+    # (buffers allocated once, the C-ABI entry called directly: with five torch.empty per call the loop is host-bound)
+    fb = comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
     fused_kernel = ctx.last_kernel()
+
+    def fused_call():
+        ctx.solve_grid_sample_device(n, M, twp, synthetic.SAMPLE_DT, S, fb[0], fb[1], fb[2], fb[3], fb[4])
+    for _ in range(10):
+        fused_call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        comp.solve_grid_sample(twp, synthetic.SAMPLE_DT, S, n_cols=N if world == 1 else None)
+    for _ in range(5 * reps):
+        fused_call()
     e1.record()
     torch.cuda.synchronize()
-    fused_us = e0.elapsed_time(e1) / reps * 1e3
+    fused_us = e0.elapsed_time(e1) / (5 * reps) * 1e3
+
+    def separate_call():      # the same outputs by the two launches, timed the same way
+        ctx.solve_grid_device(n, M, twp, fb[0], fb[1], fb[2])
+        if fb[4] is not None:
+            ctx.sample_collide_device(n, M, fb[0], fb[1], synthetic.SAMPLE_DT, S, fb[3], fb[4])
+        else:
+            ctx.sample_device(n, M, fb[0], fb[1], synthetic.SAMPLE_DT, S, 3, fb[3])
+    for _ in range(10):
+        separate_call()
+    e0.record()
+    for _ in range(5 * reps):
+        separate_call()
+    e1.record()
+    torch.cuda.synchronize()
+    separate_us = e0.elapsed_time(e1) / (5 * reps) * 1e3
     # the per-drone-grid kernel (K1: any time grids) on the same shard, outside the pipeline
     for _ in range(3):
         comp.solve(twp, tt)
@@ -543,13 +568,13 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
     comp.close()                 # drops the wrapper of the side stream before its context goes
     if side_ctx is not None:
         side_ctx.close()
-    mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial, fused_us], red_dev, use_pg)
+    mx = max_over_ranks(torch, dist, [wall] + stage_us + [gemm_us, wall_serial, fused_us, separate_us], red_dev, use_pg)
     cnt = sum_over_ranks(torch, dist, [int(status.abs().sum().item()), int(hit.sum().item()),
                                        int(mh.sum().item()) if mh is not None else 0], red_dev, use_pg)
     if rank != 0:
         return None
     wall_max, st, gemm, wall_serial_max = mx[0], dict(zip(stage_names, mx[1:1 + nst])), mx[1 + nst], mx[2 + nst]
-    fused_max = mx[3 + nst]
+    fused_max, separate_max = mx[3 + nst], mx[4 + nst]
     is_fused = fused_kernel.startswith("msnap::grid_sample_kernel")
     per = wall_max / reps
     fix = np.load(os.path.join(ROOT, "tests", "golden", "formation_golden.npz")) if n_groups == 512 else None
@@ -569,6 +594,10 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
                     ("; the pairwise pass on the whole gathered swarm on every rank" if whole else "") + ")", "rccl_ranks": world,
         "reps": reps, "warm_reps": warm, "value": N / per, "unit": "trajectories/s", "us_per_pipeline": per * 1e6,
         "stage_us": st,
+        "host_enqueue_us_per_pipeline": host_us,
+        "host_note": "host_enqueue_us_per_pipeline: Python time to enqueue one pipeline (the loop without its final drain); "
+                     "outputs are reused buffers (swarm.DeviceCompute(reuse_outputs=True)): with eleven torch.empty per "
+                     "pipeline the host needed 93 us per configs[3] pipeline and the GPU waited for it",
         "stage_us_note": "stages timed in stream order (events between them), solve and sampler as separate launches; "
                          "us_per_pipeline from a second pass without events" + (
             ", in which solve and sampler are the one fused launch of stages.solve_sample" if is_fused else "") + (
@@ -589,11 +618,12 @@ def run_formation_config(cfg, env, reps, warm, n_groups=512):
             "sample": {"kernel": "msnap::sample_kernel", "bound": "hbm",
                        "frac": sampler_bytes(n_max, M, order, S) / (st["sample"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
             "solve_sample": {"kernel": fused_kernel if is_fused else fused_kernel + " + msnap::sample_kernel",
-                             "fused": is_fused, "us": fused_max, "separate_us": st["solve"] + st["sample"], "bound": "hbm",
+                             "fused": is_fused, "us": fused_max, "separate_us": separate_max, "bound": "hbm",
                              # one launch: waypoints in; coefficients, durations, status and positions out (the
                              # sampler's read-back of the coefficients stays in LDS)
                              "frac": (algorithmic_bytes(n_max, M, order) + n_max * S * 24) / (fused_max * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                             "note": "msnap_solve_grid_sample_device, what the pipeline as run uses: the fp64 MFMA "
+                             "note": "msnap_solve_grid_sample_device, what the pipeline as run uses (us: back to back on "
+                                     "preallocated buffers; separate_us: msnap_solve_grid_device + the sampler the same way): the fp64 MFMA "
                                      "product and the Horner loops in one launch up to 11 segments (coefficients through "
                                      "LDS, outputs bit-identical to the two stages -- asserted here on every run); longer "
                                      "paths gain nothing from it and run the two kernels"},
@@ -961,6 +991,10 @@ def main():
         wps, ts = swarm(2, args.drones, M, shared_times=True)
         ctx.prepare_grid(ts)
         gsmall = GridBatch(torch, ctx, wps, M, order, device)
+        # (twice, the second pass is reported: this leg follows the saturated leg's host-side parity check and a 3 GB
+        # free, and a 6 ms replay right after that idle stretch has been measured at 9 us per step instead of 2.9 on
+        # clocks that had not come back up)
+        timed_steps(torch, dist, gsmall, ctx, args.steps, args.warmup, use_graph, 1)
         _, g_ms = timed_steps(torch, dist, gsmall, ctx, args.steps, args.warmup, use_graph, 1)
         gk_small = ctx.last_kernel()
         assert int(gsmall.status.abs().sum().item()) == 0

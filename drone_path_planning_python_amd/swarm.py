@@ -46,9 +46,16 @@ class DeviceCompute:
     main stream wait for it: the sweep overlaps the all-gather and the pairwise pass, whose launch ends
     with SIMDs running out of shares."""
 
-    def __init__(self, ctx, torch_module, side_ctx=None):
+    _reuse = None      # (class default: no output reuse)
+
+    def __init__(self, ctx, torch_module, side_ctx=None, reuse_outputs=False):
+        """`reuse_outputs`: every method hands back the SAME output tensors on each call with the same shapes (valid
+        until its next call) instead of allocating new ones -- for a loop that consumes a pass's results before it
+        starts the next: eleven `torch.empty` per formation pipeline are ~30 us of host time, as much as the host has
+        to spare beside 80 us of kernels."""
         self.ctx = ctx
         self.torch = torch_module
+        self._reuse = {} if reuse_outputs else None
         self.device = torch_module.device("cuda", ctx.device_id)
         # run on torch's current stream so the collective and the kernels order naturally
         self.main = torch_module.cuda.current_stream(self.device)
@@ -66,13 +73,22 @@ class DeviceCompute:
         self._mesh_pending = None
         self._whole_ok = {}      # (n_total, n_samples, world) -> {"ok": the whole-swarm pass pays, "since": passes since decided}
 
+    def _out(self, name, shape, dtype):
+        if self._reuse is None:
+            return self.torch.empty(shape, dtype=dtype, device=self.device)
+        key = (name, tuple(shape), dtype)
+        buf = self._reuse.get(key)
+        if buf is None:
+            buf = self._reuse[key] = self.torch.empty(shape, dtype=dtype, device=self.device)
+        return buf
+
     def solve(self, wp, t):
         torch = self.torch
         n, m, _ = wp.shape
         M = m - 1
-        coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
-        dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
-        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        coef = self._out("solve.coef", (n, M, 4, self.ctx.ncoef), torch.float64)
+        dur = self._out("solve.dur", (n, M), torch.float64)
+        status = self._out("solve.status", (n,), torch.int32)
         if n:
             self.ctx.solve_batch_device(n, M, wp, t, t.dim() == 1, coef, dur, status)
         return coef, dur, status
@@ -86,9 +102,9 @@ class DeviceCompute:
         # (the library refuses a segment count that is not the prepared grid's; the tensor's shape is checked here)
         if wp.dim() != 3 or wp.shape[2] != 4 or m != self.ctx.grid_waypoints():
             raise ValueError(f"solve_grid: wp must be [n, {self.ctx.grid_waypoints()}, 4] for the prepared grid, got {tuple(wp.shape)}")
-        coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
-        dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
-        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        coef = self._out("solve_grid.coef", (n, M, 4, self.ctx.ncoef), torch.float64)
+        dur = self._out("solve_grid.dur", (n, M), torch.float64)
+        status = self._out("solve_grid.status", (n,), torch.int32)
         if n:
             self.ctx.solve_grid_device(n, M, wp, coef, dur, status)
         return coef, dur, status
@@ -96,7 +112,7 @@ class DeviceCompute:
     def sample(self, coef, dur, dt, n_samples):
         torch = self.torch
         n, M = dur.shape
-        pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
+        pos = self._out("sample.pos", (n, n_samples, 3), torch.float64)
         if n:
             self.ctx.sample_device(n, M, coef, dur, dt, n_samples, 3, pos)
         return pos
@@ -111,8 +127,8 @@ class DeviceCompute:
         n, M = dur.shape
         if n_cols is not None and not self.ctx.collide_reads_rows_t(n, 0, n_cols, n_samples):
             return self.sample(coef, dur, dt, n_samples), None
-        pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
-        pos_t = torch.empty((self.ctx.collide_rows_t_doubles(n, n_samples),), dtype=torch.float64, device=self.device)
+        pos = self._out("sample_rows_t.pos", (n, n_samples, 3), torch.float64)
+        pos_t = self._out("sample_rows_t.pos_t", (self.ctx.collide_rows_t_doubles(n, n_samples),), torch.float64)
         if n:
             self.ctx.sample_collide_device(n, M, coef, dur, dt, n_samples, pos, pos_t)
         return pos, pos_t
@@ -126,13 +142,13 @@ class DeviceCompute:
         M = m - 1
         if wp.dim() != 3 or wp.shape[2] != 4 or m != self.ctx.grid_waypoints():
             raise ValueError(f"solve_grid_sample: wp must be [n, {self.ctx.grid_waypoints()}, 4] for the prepared grid, got {tuple(wp.shape)}")
-        coef = torch.empty((n, M, 4, self.ctx.ncoef), dtype=torch.float64, device=self.device)
-        dur = torch.empty((n, M), dtype=torch.float64, device=self.device)
-        status = torch.empty((n,), dtype=torch.int32, device=self.device)
-        pos = torch.empty((n, n_samples, 3), dtype=torch.float64, device=self.device)
+        coef = self._out("solve_grid_sample.coef", (n, M, 4, self.ctx.ncoef), torch.float64)
+        dur = self._out("solve_grid_sample.dur", (n, M), torch.float64)
+        status = self._out("solve_grid_sample.status", (n,), torch.int32)
+        pos = self._out("solve_grid_sample.pos", (n, n_samples, 3), torch.float64)
         pos_t = None
         if n_cols is not None and self.ctx.collide_reads_rows_t(n, 0, n_cols, n_samples):
-            pos_t = torch.empty((self.ctx.collide_rows_t_doubles(n, n_samples),), dtype=torch.float64, device=self.device)
+            pos_t = self._out("solve_grid_sample.pos_t", (self.ctx.collide_rows_t_doubles(n, n_samples),), torch.float64)
         if n:
             self.ctx.solve_grid_sample_device(n, M, wp, dt, n_samples, coef, dur, status, pos, pos_t)
         return coef, dur, status, pos, pos_t
@@ -140,9 +156,9 @@ class DeviceCompute:
     def collide(self, pos_rows, row_offset, pos_all, radius, rows_t=None):
         torch = self.torch
         r = pos_rows.shape[0]
-        md = torch.empty((r,), dtype=torch.float64, device=self.device)
-        partner = torch.empty((r,), dtype=torch.int32, device=self.device)
-        hit = torch.empty((r,), dtype=torch.int32, device=self.device)
+        md = self._out("collide.md", (r,), torch.float64)
+        partner = self._out("collide.partner", (r,), torch.int32)
+        hit = self._out("collide.hit", (r,), torch.int32)
         if r and rows_t is not None:
             self.ctx.formation_collide_t_device(r, row_offset, pos_all.shape[0], pos_rows.shape[1], rows_t, pos_rows,
                                                 pos_all, radius, md, partner, hit)
@@ -208,7 +224,7 @@ class DeviceCompute:
         """This rank's part of the pass over the whole swarm: uint8 [formation_part_bytes(N)] (squared minima
         of every drone over the pairs of this part, then the partners)."""
         n = pos_all.shape[0]
-        out = self.torch.empty((self.ctx.formation_part_bytes(n),), dtype=self.torch.uint8, device=self.device)
+        out = self._out("collide_part.out", (self.ctx.formation_part_bytes(n),), self.torch.uint8)
         if n:
             self.ctx.formation_collide_part_device(n, pos_all.shape[1], pos_all, part, n_parts, out)
         return out
@@ -216,9 +232,9 @@ class DeviceCompute:
     def collide_finish(self, parts, n_total, row_offset, n_rows, radius):
         """Fold the gathered parts (uint8 [P, formation_part_bytes(N)]) for the rows this rank owns."""
         torch = self.torch
-        md = torch.empty((n_rows,), dtype=torch.float64, device=self.device)
-        partner = torch.empty((n_rows,), dtype=torch.int32, device=self.device)
-        hit = torch.empty((n_rows,), dtype=torch.int32, device=self.device)
+        md = self._out("collide_finish.md", (n_rows,), torch.float64)
+        partner = self._out("collide_finish.partner", (n_rows,), torch.int32)
+        hit = self._out("collide_finish.hit", (n_rows,), torch.int32)
         if n_rows:
             self.ctx.formation_collide_finish_device(n_total, parts.shape[0], parts, row_offset, n_rows, radius,
                                                      md, partner, hit)
@@ -228,8 +244,8 @@ class DeviceCompute:
         torch = self.torch
         n = pos.shape[0]
         if md is None:
-            md = torch.empty((n,), dtype=torch.float64, device=self.device)
-            hit = torch.empty((n,), dtype=torch.int32, device=self.device)
+            md = self._out("mesh.md", (n,), torch.float64)
+            hit = self._out("mesh.hit", (n,), torch.int32)
         if n:
             ctx.mesh_sweep_device(n, pos.shape[1], pos, tris.shape[0], tris, radius, md, hit)
         return md, hit
@@ -250,8 +266,8 @@ class DeviceCompute:
             self._mesh_pending = (self.mesh(pos, tris, radius), None)
             return
         n = pos.shape[0]
-        md = self.torch.empty((n,), dtype=self.torch.float64, device=self.device)
-        hit = self.torch.empty((n,), dtype=self.torch.int32, device=self.device)
+        md = self._out("mesh.md", (n,), self.torch.float64)
+        hit = self._out("mesh.hit", (n,), self.torch.int32)
         self.side.wait_stream(self.main)            # the samples (and the mesh) are ready
         self._mesh_pending = (self._mesh_on(self.side_ctx, pos, tris, radius, md, hit), (pos, tris))
 

@@ -750,3 +750,42 @@ def test_solve_and_sampler_in_one_launch(order, n, m, S, fused):
         torch.cuda.synchronize()
     finally:
         ctx.close()
+
+
+def test_reused_outputs_are_the_same_tensors_with_the_same_results(ctx7):
+    """swarm.DeviceCompute(reuse_outputs=True): every method hands back the same output tensors on each call (valid
+    until its next call); the results are those of the allocating form, and two methods never share a buffer (the
+    pairwise pass's min_dist and the mesh sweep's have the same shape)."""
+    import torch
+    from drone_path_planning_python_amd import swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    n, m, S = 300, 10, 40
+    wp, _ = swarm(31, n, m)
+    wp[..., :3] *= 0.3
+    t = np.linspace(0.0, 10.0, m + 1)
+    ctx7.prepare_grid(t)
+    d_wp = torch.from_numpy(wp).cuda()
+    tris = torch.from_numpy(np.random.default_rng(5).uniform(-3, 3, size=(20, 3, 3))).cuda()
+    plain, reuse = sw.DeviceCompute(ctx7, torch), sw.DeviceCompute(ctx7, torch, reuse_outputs=True)
+    try:
+        ref = plain.solve_grid_sample(d_wp, 0.1, S, n_cols=n)
+        a = reuse.solve_grid_sample(d_wp, 0.1, S, n_cols=n)
+        b = reuse.solve_grid_sample(d_wp, 0.1, S, n_cols=n)
+        pitch = (n + 127) // 128 * 128
+        for k, (x, y, z) in enumerate(zip(ref, a, b)):
+            assert y.data_ptr() == z.data_ptr() and x.data_ptr() != y.data_ptr()
+            xs, ys = x.cpu().numpy(), y.cpu().numpy()
+            if k == 4:      # the row image [S][3][pitch]: its padding rows are not written
+                xs, ys = xs.reshape(S, 3, pitch)[:, :, :n], ys.reshape(S, 3, pitch)[:, :, :n]
+            np.testing.assert_array_equal(xs, ys)
+        c1 = reuse.collide(a[3], 0, a[3], 0.2, rows_t=a[4])
+        m1 = reuse.mesh(a[3], tris, 0.2)
+        assert c1[0].data_ptr() != m1[0].data_ptr() and c1[2].data_ptr() != m1[1].data_ptr()
+        c0 = plain.collide(ref[3], 0, ref[3], 0.2, rows_t=ref[4])
+        m0 = plain.mesh(ref[3], tris, 0.2)
+        for x, y in zip(c0 + m0, c1 + m1):
+            np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+        assert reuse.collide(a[3], 0, a[3], 0.2, rows_t=a[4])[0].data_ptr() == c1[0].data_ptr()
+    finally:
+        torch.cuda.synchronize()
+        ctx7.use_own_stream()
