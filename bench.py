@@ -279,15 +279,17 @@ def concurrent_streams_leg(torch, Context, dev_index, device, wp, t, n_seg, orde
             for st in streams:
                 cap.wait_stream(st)
         torch.cuda.synchronize()
-        for _ in range(2):
+        for _ in range(5):
             graph.replay()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        graph.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1)
+        ms = float("inf")
+        for _ in range(3):      # best of three replays: this leg has measured 2.6 and 4.4 us per launch on different boxes
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = min(ms, e0.elapsed_time(e1))
         ok = all(int(b.status.abs().sum().item()) == 0 for b in batches)
         same = all(torch.equal(b.coef.view(torch.uint8), batches[0].coef.view(torch.uint8)) for b in batches[1:])
         return {"streams": n_streams, "steps": per * n_streams, "ms": ms, "us_per_step": ms * 1e3 / (per * n_streams),
@@ -1078,10 +1080,10 @@ def main():
     if rank == 0 and world == 1 and use_graph and not args.no_concurrent:
         conc = {"what": "the headline shape as several independent batches in flight: one context and stream per "
                         "batch, parallel branches of one hipGraph, every branch its own buffers (results asserted "
-                        "bit-identical across branches).  A check of the declared floor, not a second headline: if the "
-                        "serial step were bound by the kernel's own latency, independent batches would overlap and the "
-                        "rate would rise with the stream count; it does not (about 4 us per launch at any count), so "
-                        "the step is bound by the rate at which launches are dispatched",
+                        "bit-identical across branches).  Not a second headline -- the contract's step is serial -- "
+                        "but what separates the two parts of the serial step's 4.5 us: independent batches overlap "
+                        "(256 drones are 32 wavefronts on 32 of 256 CUs), and the rate they reach is what the queue "
+                        "can dispatch; the rest of the serial step is the kernel's own dependent latency",
                 "by_streams": [concurrent_streams_leg(torch, Context, dev_index, device, wp, t, M, order, args.steps, k)
                                for k in (2, 4, 8)]}
         assert all(r["all_status_ok"] and r["branches_bit_identical"] for r in conc["by_streams"])

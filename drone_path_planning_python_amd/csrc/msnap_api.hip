@@ -690,6 +690,19 @@ int msnap_formation_whole_pass_pays(msnap_ctx *ctx, int n_drones, int n_ranks, i
   return MSNAP_OK;
 }
 
+// What the pass over these drones as a whole swarm will read from the sampler's second output, put on record for that
+// pass: behind the broad phase the boxes and sort keys (true: the sampler has the samples in LDS; the pass then needs
+// no key launch), otherwise the transposed row image (false).  A buffer seen before keeps its slot.
+static bool record_handover(msnap_ctx *ctx, const double *pos_t, int n_drones, int n_samples) {
+  const bool keys = formation_collide_takes_broad_phase(ctx, n_drones, 0, n_drones, n_samples);
+  msnap_ctx::Handover *rec = nullptr;
+  for (auto &h : ctx->handover)
+    if (h.ptr == (const void *)pos_t) rec = &h;
+  if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
+  *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
+  return keys;
+}
+
 int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const double *coef, const double *dur,
                                 double dt, int n_samples, double *pos, double *pos_t) {
   if (!sample_args_ok(ctx, n_drones, n_samples, 3, dt)) return MSNAP_EINVAL;
@@ -698,14 +711,7 @@ int msnap_sample_collide_device(msnap_ctx *ctx, int n_drones, int n_seg, const d
   if (n_drones == 0 || n_samples == 0) return MSNAP_OK;
   if (!coef || !dur || !pos || !pos_t) return MSNAP_EINVAL;
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
-  // what the pass over these drones as a whole swarm will read: behind the broad phase the boxes and sort keys (the
-  // sampler has the samples in LDS; the pass then needs no key launch), otherwise the transposed row image
-  const bool keys = formation_collide_takes_broad_phase(ctx, n_drones, 0, n_drones, n_samples);
-  msnap_ctx::Handover *rec = nullptr;
-  for (auto &h : ctx->handover)
-    if (h.ptr == (const void *)pos_t) rec = &h;
-  if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
-  *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
+  const bool keys = record_handover(ctx, pos_t, n_drones, n_samples);
   return launch_sample(ctx, n_drones, n_seg, coef, dur, dt, n_samples, 3, pos, pos_t, keys);
 }
 
@@ -719,15 +725,7 @@ int msnap_solve_grid_sample_device(msnap_ctx *ctx, int n_drones, int n_seg, cons
   MSNAP_HIP(ctx, hipSetDevice(ctx->device));
   if (n_samples == 0) return launch_solve_grid(ctx, n_drones, wp, coef, dur, status);
   if (!pos) return MSNAP_EINVAL;
-  bool keys = false;
-  if (pos_t) {      // the hand-over to the pairwise pass, as msnap_sample_collide_device records it
-    keys = formation_collide_takes_broad_phase(ctx, n_drones, 0, n_drones, n_samples);
-    msnap_ctx::Handover *rec = nullptr;
-    for (auto &h : ctx->handover)
-      if (h.ptr == (const void *)pos_t) rec = &h;
-    if (!rec) rec = &ctx->handover[ctx->handover_next++ % 8];
-    *rec = {pos_t, n_drones, n_samples, keys ? 2 : 1};
-  }
+  const bool keys = pos_t && record_handover(ctx, pos_t, n_drones, n_samples);
   return launch_grid_sample(ctx, n_drones, wp, dt, n_samples, coef, dur, status, pos, pos_t, keys);
 }
 

@@ -1737,7 +1737,8 @@ collide_finish_groups_kernel(int N, const int32_t *__restrict__ oid, const int32
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   double best = INFINITY;
   int bj = -1;
-  constexpr int U = 4;      // entries of a lane in flight: 32 items of the group per round
+  constexpr int U = 8;      // entries of a lane in flight: 64 items of the group per round (a round is a dependent round
+                            // trip: configs[3] fixture 12.5 -> 11.2 us against U = 4; 16 gives no more)
   for (int q0 = 0; q0 < nA + nB; q0 += U * (kWave / kColBlock)) {
     double d[U];
     int j[U];
