@@ -101,6 +101,9 @@ int msnap_host_free(void *ptr);
  *                          a small cap makes every wave walk several tiles (the regime of a
  *                          saturating batch) on a batch the oracle checks in seconds
  *   "gemm_grid_waves"      the same for the shared-grid GEMM
+ *   "gemm_stream_waves_per_cu"  wavefronts per CU up to which the streaming GEMM (16 and more segments) slices its
+ *                          column tiles over more waves (0 = default: 16)
+ *   "no_grid_sample"       1: msnap_solve_grid_sample_device runs the two kernels where it would fuse (A/B timing)
  *   "twist_max_drones"     largest batch that takes the small-batch two-sided kernel (0 = default)
  *   "no_twist"             1: small batches stay on the one-sided kernels
  *   "twin_max_drones"      largest batch that takes the two-sided column-split throughput kernel (0 = default:
@@ -143,7 +146,7 @@ int msnap_host_free(void *ptr);
  *                          set it BEFORE msnap_get_stream() hands the handle to anybody (a wrapper around
  *                          the old handle -- e.g. torch.cuda.ExternalStream -- would dangle)
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
- * MSNAP_GEMM_GRID_WAVES, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_GEMM_STREAM_WAVES_PER_CU, MSNAP_NO_GRID_SAMPLE, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
  * MSNAP_COLLIDE_SAMPLE_PARTS, MSNAP_COLLIDE_NO_CULL, MSNAP_COLLIDE_CULL_MIN_DRONES,
  * MSNAP_COLLIDE_CULL_MODE and MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);
