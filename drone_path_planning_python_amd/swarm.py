@@ -342,7 +342,8 @@ def all_gather_parts(part_local, world: int, dist, torch, force: bool = False):
 
 def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, rank: int, dt: float,
                    n_samples: int, radius: float, dist=None, torch=None, status_local=None,
-                   mesh_tris=None, force_collectives: bool = False, force_mode: str = None) -> FormationResult:
+                   mesh_tris=None, force_collectives: bool = False, force_mode: str = None,
+                   _sampled=None) -> FormationResult:
     """Sample the local shard, exchange, evaluate this rank's part of the swarm's pairs, exchange the
     partial minima and fold them for the own rows (one rank: one symmetric launch, no exchange); with
     `mesh_tris` ([T, 3, 3]) also sweep the local shard against the mesh, started right behind the sampler
@@ -368,7 +369,9 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
             raise TypeError("formation_pass on several ranks needs compute.collide_part / collide_finish "
                             "(every pair on exactly one rank); this compute object only has collide()")
     rows_t = None
-    if not multi and hasattr(compute, "sample_rows_t"):
+    if _sampled is not None:      # (formation_pass_from_waypoints: solve and sampler were one launch)
+        pos_local, rows_t = _sampled
+    elif not multi and hasattr(compute, "sample_rows_t"):
         pos_local, rows_t = compute.sample_rows_t(coef_local, dur_local, dt, n_samples, n_cols=n_total)
     else:
         pos_local = compute.sample(coef_local, dur_local, dt, n_samples)
@@ -409,6 +412,23 @@ def formation_pass(compute, coef_local, dur_local, n_total: int, world: int, ran
                 first.__context__ = second
         raise
     return FormationResult(lo, hi, md, partner, hit, pos_all, mmd, mhit)
+
+
+def formation_pass_from_waypoints(compute, wp_local, n_total: int, world: int, rank: int, dt: float, n_samples: int,
+                                  radius: float, dist=None, torch=None, mesh_tris=None, check_status: bool = True,
+                                  force_collectives: bool = False, force_mode: str = None):
+    """`formation_pass` for a swarm on the context's prepared time grid, from the waypoints: the solve and the sampler
+    are ONE launch (`compute.solve_grid_sample`, msnap_solve_grid_sample_device), the rest is `formation_pass`.
+    Returns (FormationResult, coef, dur, status).  `check_status` reads the solve's status back before the pairwise
+    pass (one synchronisation) and refuses failed drones as `formation_pass` does; a caller that checks `status`
+    itself later passes False and keeps the stream running."""
+    lo, hi = shard_bounds(n_total, world, rank)
+    multi = world > 1 or force_collectives
+    coef, dur, status, pos, rows_t = compute.solve_grid_sample(wp_local, dt, n_samples, n_cols=None if multi else n_total)
+    res = formation_pass(compute, coef, dur, n_total, world, rank, dt, n_samples, radius, dist=dist, torch=torch,
+                         status_local=status if check_status else None, mesh_tris=mesh_tris,
+                         force_collectives=force_collectives, force_mode=force_mode, _sampled=(pos, rows_t))
+    return res, coef, dur, status
 
 
 def default_sample_count(total_duration: float, dt: float) -> int:

@@ -562,3 +562,41 @@ def test_broad_phase_on_random_shapes():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(budget=120.0, seed=5, max_cases=60, big=False) == 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,S,mesh", [(4096, 10, 91, False), (300, 8, 40, True), (3500, 20, 50, True)])
+def test_formation_pass_from_waypoints_equals_the_staged_pass(n, m, S, mesh):
+    """swarm.formation_pass_from_waypoints (solve and sampler as one launch where the library fuses them, two inside the
+    same call at 20 segments) against solve_grid -> formation_pass: the same coefficients, samples, minima, partners
+    and hits, bit for bit -- behind the broad phase (4096, 3500 drones) and without it, with and without a mesh; a
+    failed drone is refused after the solve unless the caller takes the status check on itself."""
+    import torch
+    from drone_path_planning_python_amd import Context, swarm as sw
+    from drone_path_planning_python_amd.synthetic import swarm
+    ctx = Context(order=7, max_segments=32)
+    try:
+        wp, _ = swarm(4000 + n, n, m)
+        wp[..., :3] *= 0.4
+        ctx.prepare_grid(np.linspace(0.0, 10.0, m + 1))
+        comp = sw.DeviceCompute(ctx, torch)
+        d_wp = torch.from_numpy(wp).cuda()
+        tris = torch.from_numpy(_scene()).cuda() if mesh else None
+        coef, dur, status = comp.solve_grid(d_wp)
+        a = sw.formation_pass(comp, coef, dur, n, 1, 0, 0.1, S, 0.2, torch=torch, status_local=status, mesh_tris=tris)
+        b, coef2, dur2, status2 = sw.formation_pass_from_waypoints(comp, d_wp, n, 1, 0, 0.1, S, 0.2, torch=torch, mesh_tris=tris)
+        for x, y in ((coef, coef2), (dur, dur2), (status, status2), (a.positions_all, b.positions_all), (a.min_dist, b.min_dist),
+                     (a.partner, b.partner), (a.hit, b.hit)):
+            np.testing.assert_array_equal(x.cpu().numpy().view(np.uint8), y.cpu().numpy().view(np.uint8))
+        if mesh:
+            np.testing.assert_array_equal(a.mesh_min_dist.cpu().numpy(), b.mesh_min_dist.cpu().numpy())
+            np.testing.assert_array_equal(a.mesh_hit.cpu().numpy(), b.mesh_hit.cpu().numpy())
+        bad = d_wp.clone()
+        bad[5, 1, 0] = float("nan")
+        with pytest.raises(ValueError):
+            sw.formation_pass_from_waypoints(comp, bad, n, 1, 0, 0.1, S, 0.2, torch=torch)
+        res, _, _, st = sw.formation_pass_from_waypoints(comp, bad, n, 1, 0, 0.1, S, 0.2, torch=torch, check_status=False)
+        assert int(st[5]) != 0 and np.isinf(res.min_dist[5].item()) and int(res.partner[5]) == -1
+        torch.cuda.synchronize()
+    finally:
+        ctx.close()
