@@ -78,7 +78,7 @@ static const OptionName kOptions[] = {
     {"solve_grid_waves", "MSNAP_SOLVE_GRID_WAVES"}, {"gemm_grid_waves", "MSNAP_GEMM_GRID_WAVES"},
     {"twist_max_drones", "MSNAP_TWIST_MAX_DRONES"}, {"no_twist", "MSNAP_NO_TWIST"},
     {"collide_waves_per_cu", "MSNAP_COLLIDE_WAVES_PER_CU"}, {"pipe_chunk_mb", "MSNAP_PIPE_CHUNK_MB"},
-    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"no_grid_sample", "MSNAP_NO_GRID_SAMPLE"}, {"gemm_stream_waves_per_cu", "MSNAP_GEMM_STREAM_WAVES_PER_CU"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"collide_cull_mode", "MSNAP_COLLIDE_CULL_MODE"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
+    {"collide_sample_parts", "MSNAP_COLLIDE_SAMPLE_PARTS"}, {"no_twin", "MSNAP_NO_TWIN"}, {"no_grid_sample", "MSNAP_NO_GRID_SAMPLE"}, {"gemm_stream_waves_per_cu", "MSNAP_GEMM_STREAM_WAVES_PER_CU"}, {"mesh_waves_per_cu", "MSNAP_MESH_WAVES_PER_CU"}, {"collide_no_cull", "MSNAP_COLLIDE_NO_CULL"}, {"collide_cull_min_drones", "MSNAP_COLLIDE_CULL_MIN_DRONES"}, {"collide_cull_mode", "MSNAP_COLLIDE_CULL_MODE"}, {"twin_max_drones", "MSNAP_TWIN_MAX_DRONES"},
 };
 
 void note_kernel(msnap_ctx *ctx, const char *fmt, ...) {
@@ -98,6 +98,7 @@ static int *option_slot(msnap_ctx *ctx, const char *name) {
   if (!strcmp(name, "no_twin")) return &ctx->no_twin;
   if (!strcmp(name, "no_grid_sample")) return &ctx->no_grid_sample;
   if (!strcmp(name, "gemm_stream_waves_per_cu")) return &ctx->gemm_stream_waves_per_cu;
+  if (!strcmp(name, "mesh_waves_per_cu")) return &ctx->mesh_waves_per_cu;
   if (!strcmp(name, "twin_max_drones")) return &ctx->twin_max_drones;
   if (!strcmp(name, "collide_waves_per_cu")) return &ctx->collide_waves_per_cu;
   if (!strcmp(name, "collide_sample_parts")) return &ctx->collide_sample_parts;

@@ -2869,10 +2869,12 @@ mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__
                   double radius, double *__restrict__ min_dist, int32_t *__restrict__ hit,
                   unsigned long long *__restrict__ tests_done) {
   __shared__ double sBest[16];
-  const int d = blockIdx.x;
   const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, nw = blockDim.x / kWave;
-  double best = INFINITY;
   unsigned long long done = 0;
+  // one drone per workgroup, or ("mesh_waves_per_cu") a smaller grid whose workgroups walk the drones: a sweep that
+  // runs beside another stream's kernels then leaves them wave slots and registers for as long as it runs
+  for (int d = blockIdx.x; d < N; d += gridDim.x) {
+  double best = INFINITY;
   for (int s0 = wv * kWave; s0 < S; s0 += nw * kWave) {      // one trip unless S > 1024
     const int s = s0 + lane;
     const double *p = pos + ((size_t)d * S + (s < S ? s : S - 1)) * 3;   // lanes past the end replay the last sample
@@ -2922,12 +2924,14 @@ mesh_sweep_kernel(const double *__restrict__ pos, int N, int S, const double *__
   }
   best = wave_min_f64(best);
   if (lane == 0) sBest[wv] = best;
-  __syncthreads();
+  lds_barrier();
   if (threadIdx.x == 0) {
     for (int k = 1; k < nw; ++k) best = (sBest[k] < best) ? sBest[k] : best;
     const double dist = sqrt(best);
     min_dist[d] = dist;
     hit[d] = (dist < radius) ? 1 : 0;
+  }
+  lds_barrier();      // (sBest is free for the next drone)
   }
   if (tests_done && lane == 0) atomicAdd(tests_done, done * kWave);
 }
@@ -2936,7 +2940,12 @@ int launch_mesh_sweep(msnap_ctx *ctx, int n_drones, int n_samples, const double 
                       const double *tris, double radius, double *min_dist, int32_t *hit) {
   int waves = (n_samples + kWave - 1) / kWave;
   if (waves > 16) waves = 16;
-  hipLaunchKernelGGL(mesh_sweep_kernel, dim3(n_drones), dim3(waves * kWave), 0, ctx->stream, pos, n_drones,
+  int blocks = n_drones;
+  if (ctx->mesh_waves_per_cu > 0) {      // msnap_set_option: room for other streams' workgroups beside the sweep
+    const int cap = ctx->n_cu * ctx->mesh_waves_per_cu / waves;
+    blocks = blocks < cap ? blocks : (cap > 0 ? cap : 1);
+  }
+  hipLaunchKernelGGL(mesh_sweep_kernel, dim3(blocks), dim3(waves * kWave), 0, ctx->stream, pos, n_drones,
                      n_samples, tris, n_tris, radius, min_dist, hit, (unsigned long long *)ctx->mesh_tests);
   MSNAP_HIP(ctx, hipGetLastError());
   return MSNAP_OK;

@@ -121,6 +121,7 @@ struct msnap_ctx {
   } handover[8];
   int handover_next = 0;
   int collide_last_sym = 0;     // "collide_last_sym" (read): 1 if the last msnap_formation_collide evaluated its own-range pairs once
+  int mesh_waves_per_cu = 0;    // "mesh_waves_per_cu": wavefronts per CU the mesh sweep's grid is capped at (0: one workgroup per drone)
   int own_stream_priority = 0;  // "own_stream_priority": 0 default, 1 lowest, 2 highest (re-creates own_stream)
   msnap::RetiredBuf *retired = nullptr;   // blocks kept alive for graphs captured before they were outgrown
   char hip_err[256] = {0};

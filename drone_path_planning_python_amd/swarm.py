@@ -68,6 +68,10 @@ class DeviceCompute:
             # the side context's own stream at the lowest priority: the sweep's workgroups are dispatched
             # when the main stream's kernels have none waiting, i.e. into the end of the pairwise launch
             side_ctx.set_option("own_stream_priority", 1)
+            # ... and as a grid of 12 waves per CU that walks the drones: one workgroup per drone holds every wave slot
+            # of the chip for the sweep's whole run, and the main stream's next kernel waits for its end
+            if side_ctx.get_option("mesh_waves_per_cu") == 0:
+                side_ctx.set_option("mesh_waves_per_cu", 12)
             side_ctx.use_own_stream()
             self.side = torch_module.cuda.ExternalStream(side_ctx.stream(), device=self.device)
         self._mesh_pending = None

@@ -134,6 +134,10 @@ int msnap_host_free(void *ptr);
  *                          counts the context's previous pass over a swarm of this size left in page-locked memory
  *                          (read without synchronising; a pass without such counts takes the shares).  Results are
  *                          identical either way
+ *   "mesh_waves_per_cu"    wavefronts per CU msnap_mesh_sweep's grid is capped at (0 = one workgroup per drone: a large
+ *                          sweep then holds every wave slot of the chip for its whole run).  A sweep on a second
+ *                          stream beside other kernels leaves them room with 8..12 (it runs longer itself:
+ *                          4096 drones x 96 samples x 68 triangles 33 -> 40..45 us, the pipeline around it 106 -> 102)
  *   "mesh_count_tests"     1: count the point-triangle tests msnap_mesh_sweep evaluates (the ones
  *                          its bounding-box cull does not skip); msnap_get_option returns the count
  *                          since the option was last set (and synchronises the stream); 0: off
@@ -146,7 +150,7 @@ int msnap_host_free(void *ptr);
  *                          set it BEFORE msnap_get_stream() hands the handle to anybody (a wrapper around
  *                          the old handle -- e.g. torch.cuda.ExternalStream -- would dangle)
  * msnap_create seeds them once from the environment variables MSNAP_SOLVE_GRID_WAVES,
- * MSNAP_GEMM_GRID_WAVES, MSNAP_GEMM_STREAM_WAVES_PER_CU, MSNAP_NO_GRID_SAMPLE, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
+ * MSNAP_GEMM_GRID_WAVES, MSNAP_GEMM_STREAM_WAVES_PER_CU, MSNAP_NO_GRID_SAMPLE, MSNAP_MESH_WAVES_PER_CU, MSNAP_TWIST_MAX_DRONES, MSNAP_NO_TWIST, MSNAP_NO_TWIN, MSNAP_TWIN_MAX_DRONES, MSNAP_COLLIDE_WAVES_PER_CU,
  * MSNAP_COLLIDE_SAMPLE_PARTS, MSNAP_COLLIDE_NO_CULL, MSNAP_COLLIDE_CULL_MIN_DRONES,
  * MSNAP_COLLIDE_CULL_MODE and MSNAP_PIPE_CHUNK_MB; nothing on a launch path reads the environment. */
 int msnap_set_option(msnap_ctx *ctx, const char *name, long value);

@@ -240,6 +240,34 @@ def test_mesh_sweep_edges(ctx7, n, s, t):
         assert np.isinf(md).all() and not hit.any()
 
 
+@pytest.mark.parametrize("cap", [1, 3, 12])
+def test_mesh_sweep_as_a_capped_grid_walks_all_drones(ctx7, cap):
+    """ "mesh_waves_per_cu": the sweep as a grid smaller than the swarm whose workgroups walk the drones (what a sweep
+    beside another stream's kernels runs as): bit for bit the one-workgroup-per-drone results, incl. a drone count that
+    is not a multiple of the grid, two waves per workgroup, NaN paths and the test counter."""
+    rng = np.random.default_rng(40 + cap)
+    n, s = 2003, 100
+    pos = rng.uniform(-3.0, 3.0, size=(n, s, 3))
+    pos[17] = np.nan
+    pos[1999, 40:] = np.inf
+    tris = rng.uniform(-4.0, 4.0, size=(70, 3, 3))
+    ref = ctx7.mesh_sweep(pos, tris, 0.4)
+    ctx7.set_option("mesh_count_tests", 1)
+    ctx7.mesh_sweep(pos, tris, 0.4)
+    tests_ref = ctx7.get_option("mesh_count_tests")
+    try:
+        ctx7.set_option("mesh_waves_per_cu", cap)
+        ctx7.set_option("mesh_count_tests", 1)
+        got = ctx7.mesh_sweep(pos, tris, 0.4)
+        assert ctx7.get_option("mesh_count_tests") == tests_ref > 0
+    finally:
+        ctx7.set_option("mesh_waves_per_cu", 0)
+        ctx7.set_option("mesh_count_tests", 0)
+    np.testing.assert_array_equal(got[0], ref[0])
+    np.testing.assert_array_equal(got[1], ref[1])
+    assert np.isinf(got[0][17]) and not got[1][17]
+
+
 def test_mesh_sweep_against_oracle(ctx7, tmp_path):
     from drone_path_planning_python_amd import stl
     wall = stl.box_mesh((-2, 3.9, 0), (2, 4.1, 1.6))        # env-scene-ltu-experiment.stl's box
