@@ -227,14 +227,19 @@ def timed_steps(torch, dist, batch, ctx, steps, warmup, use_graph, world):
         torch.cuda.synchronize()
     for _ in range(warmup):
         batch.step()
+    # the events exist (and have been recorded once) before the clock starts: torch creates the HIP event at its first
+    # record(), and two creations inside a 20-step region were ~10 us of its ~125 (tools/replay_overhead.py: the first
+    # region of a process against the later ones)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
     if graph is not None:
         graph.replay()           # one untimed replay (graph upload)
+    ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
     if graph is not None:

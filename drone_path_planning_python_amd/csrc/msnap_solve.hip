@@ -423,12 +423,21 @@ __device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_bas
 // dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
 __device__ __forceinline__ void store_durations(const double *sTraw, int shared_times, int tpitch, int M,
                                                 int nvalid, int lane, double *__restrict__ dur_tile) {
+  // The trip count is WAVE-UNIFORM (a scalar loop around a predicated body), not `for (e = lane; e < cnt; e += 64)`:
+  // a loop the lanes leave one by one ends with exec == 0, and the compiler put register-pressure copies of values
+  // that live across it (v_accvgpr_write_b32 of lane + 64 / lane + 128, solve_kernel_twin<5, 20>; the scratch spills of
+  // round 3's two-sided 16-segment instance) into that exit block IN FRONT of the instruction that restores exec --
+  // they wrote no lane, the next tile's prefetch indices were garbage: "Memory access fault by GPU" (DESIGN.md 9.3;
+  // tools/check_exec_isa.py now refuses a build with such a copy under a reduced exec mask)
   const int cnt = nvalid * M;
-  for (int e = lane; e < cnt; e += kWave) {
-    const int dl = e / M;
-    const int i = e - dl * M;
-    const double *lt = sTraw + (shared_times ? 0 : dl * tpitch);
-    dur_tile[e] = lt[i + 1] - lt[i];
+  for (int e0 = 0; e0 < cnt; e0 += kWave) {
+    const int e = e0 + lane;
+    if (e < cnt) {
+      const int dl = e / M;
+      const int i = e - dl * M;
+      const double *lt = sTraw + (shared_times ? 0 : dl * tpitch);
+      dur_tile[e] = lt[i + 1] - lt[i];
+    }
   }
 }
 
@@ -1052,7 +1061,7 @@ inline size_t twin_lds_bytes(int khalf, int n_seg) {
 template <int K, int M>
 constexpr int kTwinZInLds = (K == 4 && M >= 17) ? 4 : 0;
 template <int K, int M>
-constexpr int kTwinWaves = 2;
+constexpr int kTwinWaves = (K == 5 && M >= 13) ? 1 : 2;   // (order 9, 13..20 segments: 512 registers per lane, see kTwinMaxSeg)
 
 // cross-tile input prefetch of the twin kernel: the hand-issued loads and exact wait of solve_kernel_reg
 // (stage_load_asm / stage_wait_asm), for 8 drones per tile and a compile-time segment count
@@ -1733,9 +1742,11 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 constexpr int kTwistMaxSeg = 24;    // twisted variant, order 7: one instance per n_seg in 2..24
 constexpr int kTwistMaxSeg9 = 12;   // order 9: 2..12
 
-constexpr int kTwinMaxSeg = 12;    // order 9, batches beyond one wave per CU: solve_kernel_twin (13-20 segments need scratch at 256
-                                   // registers -- 10-130 dwords -- and win only up to 8192 drones: 8192 x 20 28.1 against 32.4 us; not shipped:
-                                   // no kernel of the library uses scratch)
+constexpr int kTwinMaxSeg = 20;    // order 9: solve_kernel_twin for 4..20 segments.  13..20 segments do not fit the 256 registers of two
+                                   // waves per SIMD (290..402 as built) and are instances for ONE wave per SIMD: the compiler keeps the
+                                   // excess in accumulation registers (10..146; no scratch).  Against solve_kernel_reg<5, 20> (also one wave
+                                   // per SIMD): 65 536 x 20: 136-143 against 187 us, 2^20 x 20: 1.80 against 2.32 ms = 54 % against 42 % of
+                                   // the HBM peak, 8192 x 20: 19.6 against 32.1 us (profiles/r04_order9_long.txt); 13 segments tie at 2^20
 constexpr int kTwinMaxSeg7 = 20;   // order 7 (19 and 20 segments: z of the first knots in LDS instead of registers)
 constexpr int kRegMaxSeg = 10;    // n_seg <= 10 takes the register-resident variant (2 waves per SIMD) ...
 constexpr int kRegMaxSeg2 = 20;   // ... 11 <= n_seg <= 20 a second instance at one wave per SIMD
@@ -1807,7 +1818,8 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
     if constexpr (K == 5) {
       switch (M) {
         MSNAP_TWIN(4) MSNAP_TWIN(5) MSNAP_TWIN(6) MSNAP_TWIN(7) MSNAP_TWIN(8) MSNAP_TWIN(9) MSNAP_TWIN(10)
-        MSNAP_TWIN(11) MSNAP_TWIN(12)
+        MSNAP_TWIN(11) MSNAP_TWIN(12) MSNAP_TWIN(13) MSNAP_TWIN(14) MSNAP_TWIN(15) MSNAP_TWIN(16) MSNAP_TWIN(17)
+        MSNAP_TWIN(18) MSNAP_TWIN(19) MSNAP_TWIN(20)
         default: return MSNAP_EINVAL;   // unreachable: the range is checked above
       }
     } else {

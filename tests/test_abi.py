@@ -88,6 +88,22 @@ def test_prefetch_wait_counts_match_the_code_object():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_no_register_pressure_copy_under_a_reduced_exec_mask():
+    """tools/check_exec_isa.py on the objects of this build: the compiler's copies of values that do not fit the 256
+    architectural VGPRs (v_accvgpr_write_b32; scratch stores) must not sit inside a divergent region -- under a reduced
+    exec mask they save only some lanes.  Round 4 (and, by every sign, round 3's abort) was such a copy in the exit
+    block of a loop the lanes leave one by one: the cross-tile prefetch of solve_kernel_twin<5, 20> then read at
+    base + 16 * garbage."""
+    import subprocess
+    import sys
+    objs = [os.path.join(ROOT, "drone_path_planning_python_amd", "csrc", f) for f in ("msnap_solve.o", "msnap_aux.o", "msnap_grid.o")]
+    if not all(os.path.exists(o) for o in objs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no object files / ROCm LLVM tools here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_exec_isa.py")] + objs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("none under a reduced exec mask") == 3, r.stdout
+
+
 def test_no_kernel_of_the_library_uses_scratch():
     """Code-object metadata of every kernel in libmsnap.so: .private_segment_fixed_size == 0.  Spilled registers cost
     memory round trips inside the hot loops, and scratch ties a launch to per-queue state of the runtime (an order-9

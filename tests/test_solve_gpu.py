@@ -202,7 +202,7 @@ def test_order9_against_extended_precision(gold9, name):
             errs[ctx.last_kernel()] = norm_rel(coef, ref)
     print(name, {k: f"{v:.1e}" for k, v in errs.items()})
     assert errs and max(errs.values()) <= TIGHT9, errs
-    if 4 <= M <= 12:
+    if 4 <= M <= 20:      # (13..20 segments: the one-wave-per-SIMD instances of round 4)
         assert any("solve_kernel_twin<5" in k for k in errs), errs
 
 
@@ -216,6 +216,56 @@ def test_order9_against_generalised_oracle(ctx9, m):
     ref, rdur = _c_ref(wp, t, ncoef=10)
     assert norm_rel(coef, ref) <= TIGHT9
     np.testing.assert_array_equal(dur, rdur)
+
+
+@pytest.mark.parametrize("m", [13, 14, 15, 16, 17, 18, 19, 20])
+def test_order9_long_paths_inside_a_guarded_arena(m):
+    """solve_kernel_twin<5, 13..20> (one wave per SIMD, up to 146 accumulation registers as spill space) with every
+    device buffer inside a pattern-filled arena: no byte outside the outputs changes, and the outputs equal the
+    one-sided register kernel's and the C oracle's -- for whole tiles, every partial-tile size, one tile per wave and
+    several tiles per wave (the cross-tile prefetch).  The first build of these instances read its prefetch indices
+    from accumulation registers that a copy under exec == 0 had never written: `Memory access fault by GPU` at
+    base + 16 * garbage, even for 8 drones (tools/check_exec_isa.py is the build-time tripwire)."""
+    import torch
+    from drone_path_planning_python_amd import Context
+    from drone_path_planning_python_amd.synthetic import swarm
+    dev = torch.device("cuda", 0)
+    PAT, GAP = 0xA5, 1 << 16
+    with Context(order=9, max_segments=64) as ctx, Context(order=9, max_segments=64) as ref_ctx:
+        ref_ctx.set_option("no_twist", 1)
+        ref_ctx.set_option("no_twin", 1)
+        for n, waves in ((1, 0), (4, 0), (7, 0), (8, 0), (9, 0), (17, 0), (100, 3), (1029, 16)):
+            wp, t = swarm(900 + 31 * m + n, n, m)
+            sizes = {"wp": wp.nbytes, "t": t.nbytes, "coef": n * m * 40 * 8, "dur": n * m * 8, "status": n * 4}
+            off, cur = {}, 4 << 20
+            for k in sizes:
+                off[k] = cur
+                cur += (sizes[k] + GAP + 255) & ~255
+            arena = torch.full((cur + (4 << 20),), PAT, dtype=torch.uint8, device=dev)
+            view = lambda k, dt: arena[off[k]:off[k] + sizes[k]].view(dt)      # noqa: E731
+            view("wp", torch.float64).copy_(torch.from_numpy(wp.reshape(-1)))
+            view("t", torch.float64).copy_(torch.from_numpy(t.reshape(-1)))
+            torch.cuda.synchronize()
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.set_option("solve_grid_waves", waves)
+            base = arena.data_ptr()
+            ctx.solve_batch_device(n, m, base + off["wp"], base + off["t"], False, base + off["coef"],
+                                   base + off["dur"], base + off["status"])
+            torch.cuda.synchronize()
+            assert ctx.last_kernel() == f"msnap::solve_kernel_twin<5, {m}>"
+            ctx.use_own_stream()
+            mask = arena != PAT
+            for k in off:
+                mask[off[k]:off[k] + sizes[k]] = False
+            assert not bool(mask.any()), f"stray writes at {torch.nonzero(mask).flatten()[:8].tolist()} (n = {n})"
+            coef = view("coef", torch.float64).cpu().numpy().reshape(n, m, 4, 10)
+            assert not view("status", torch.int32).any()
+            np.testing.assert_array_equal(view("dur", torch.float64).cpu().numpy().reshape(n, m), np.diff(t, axis=1))
+            rcoef, _, rstatus = ref_ctx.solve_batch(wp, t)
+            assert ref_ctx.last_kernel() == "msnap::solve_kernel_reg<5, 20>" and (rstatus == 0).all()
+            assert norm_rel(coef, rcoef) <= TIGHT9, (n, waves)
+            oref, _ = _c_ref(wp, t, ncoef=10)
+            assert norm_rel(coef, oref) <= TIGHT9, (n, waves)
 
 
 def test_long_lived_context_after_many_short_lived_ones(ctx9, gold9):

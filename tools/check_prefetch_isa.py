@@ -190,8 +190,8 @@ def main():
             t = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>\s*$", ln)
             base = kernels[cur][0][1] if kernels[cur] else int(m.group(1), 16)
             kernels[cur].append((text, int(m.group(1), 16), base + int(t.group(1), 16) if t else None))
-    if len(kernels) != 30:
-        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 26 solve_kernel_twin instances, found {len(kernels)}")
+    if len(kernels) != 38:
+        print(f"check_prefetch_isa: expected 4 solve_kernel_reg + 34 solve_kernel_twin instances, found {len(kernels)}")
         return 1
     res = {n: check_kernel(n, b) for n, b in sorted(kernels.items())}
     bad = [e for e in res.values() if e]
