@@ -935,7 +935,8 @@ def test_last_kernel_reports_the_launched_instance():
         ctx.set_option("no_twist", 1)
         for m, want in [(10, "msnap::solve_kernel_twin<5, 10>"), (6, "msnap::solve_kernel_twin<5, 6>"),
                         (7, "msnap::solve_kernel_twin<5, 7>"), (2, "msnap::solve_kernel_reg<5, 10>"),
-                        (16, "msnap::solve_kernel_reg<5, 20>")]:
+                        (16, "msnap::solve_kernel_twin<5, 16>"),        # round 4: 13..20 segments, one wave per SIMD
+                        (21, "msnap::solve_kernel<5, false>")]:
             wp, t = swarm(80 + m, 100, m)
             ctx.solve_batch(wp, t)
             assert ctx.last_kernel() == want
@@ -943,6 +944,9 @@ def test_last_kernel_reports_the_launched_instance():
         wp, t = swarm(90, 100, 10)
         ctx.solve_batch(wp, t)
         assert ctx.last_kernel() == "msnap::solve_kernel_reg<5, 10>"
+        wp, t = swarm(91, 100, 16)
+        ctx.solve_batch(wp, t)
+        assert ctx.last_kernel() == "msnap::solve_kernel_reg<5, 20>"
 
 
 # ---------------------------------------------------------------------------

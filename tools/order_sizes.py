@@ -2,7 +2,8 @@
 """The solve over batch sizes (configs[4] sharded over 1..8 GPUs is 65536..8192 drones per rank), order 9 or -- with
 PROBE_ORDER=7 -- order 7: the launcher's choice against the alternatives ("no_twist" keeps small batches off the
 two-sided latency kernel, "no_twin" keeps larger ones on solve_kernel_reg), each under a hipGraph of 50 launches.
-   [PROBE_ORDER=7] python tools/order_sizes.py [segments=10] [N ...]"""
+   [PROBE_ORDER=7] [PROBE_GRIDS="1024 2048 ..."] python tools/order_sizes.py [segments=10] [N ...]
+PROBE_GRIDS: the launcher's choice again with the persistent grid forced to these wave counts (solve_grid_waves)."""
 import os
 import sys
 
@@ -25,7 +26,8 @@ for N in sizes:
     dur = torch.empty((N, M), dtype=torch.float64, device=dev)
     st = torch.empty((N,), dtype=torch.int32, device=dev)
     bytes_ = N * (8 * 5 * (M + 1) + 8 * M * (1 + 4 * (order + 1)))
-    for opts in ({}, {"no_twist": 1}, {"no_twist": 1, "no_twin": 1}):
+    grids = [{"solve_grid_waves": int(g)} for g in os.environ.get("PROBE_GRIDS", "").split()]
+    for opts in [{}, {"no_twist": 1}, {"no_twist": 1, "no_twin": 1}] + grids:
         ctx = Context(0, order, 64)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         for k, v in opts.items():
@@ -47,7 +49,8 @@ for N in sizes:
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
-        print(f"order {order} {N:6d} x {M}: {ctx.last_kernel():40s} {us:7.2f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak "
+        tag = f" grid {opts['solve_grid_waves']}" if "solve_grid_waves" in opts else ""
+        print(f"order {order} {N:6d} x {M}: {ctx.last_kernel() + tag:40s} {us:7.2f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak "
               f"({N / us:.1f} traj/us)", flush=True)
         ctx.use_own_stream()
         ctx.close()
