@@ -104,6 +104,58 @@ def test_no_register_pressure_copy_under_a_reduced_exec_mask():
     assert r.stdout.count("none under a reduced exec mask") == 3, r.stdout
 
 
+def test_the_exec_check_sees_the_round_4_fault_pattern():
+    """tools/check_exec_isa.walk on the instruction shapes of the faulty build (solve_kernel_twin<5, 20>, round 4): a
+    loop the lanes leave one by one, the copies in its exit block in front of the restore -- reported; the same copies
+    behind the restore, and copies around a wave-uniform loop with a predicated body -- not reported."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_exec_isa as chk
+
+    def body(lines):
+        out, labels = [], {}
+        for ln in lines:
+            if ln.endswith(":"):
+                labels[ln[:-1]] = 0x1000 + 4 * len(out)
+            else:
+                out.append(ln)
+        res = []
+        for i, ln in enumerate(out):
+            ins, _, lab = ln.partition(" -> ")
+            res.append((ins, 0x1000 + 4 * i, labels[lab] if lab else None))
+        return res
+
+    faulty = body(["v_add_u32_e32 v22, 64, v28",
+                   "s_and_saveexec_b64 s[4:5], s[0:1]",
+                   "s_cbranch_execz 58 -> join",
+                   "loop:",
+                   "global_store_dwordx2 v[0:1], v[4:5], off",
+                   "s_or_b64 s[6:7], s[0:1], s[6:7]",
+                   "s_andn2_b64 exec, exec, s[6:7]",
+                   "s_cbranch_execnz 65501 -> loop",
+                   "v_accvgpr_write_b32 a4, v18",
+                   "v_accvgpr_write_b32 a2, v22",
+                   "join:",
+                   "s_or_b64 exec, exec, s[4:5]",
+                   "s_endpgm"])
+    found = chk.walk(faulty)
+    assert sorted(f[0] for f in found) == ["v_accvgpr_write_b32 a2, v22", "v_accvgpr_write_b32 a4, v18"], found
+    behind = body(faulty_lines := ["s_and_saveexec_b64 s[4:5], s[0:1]", "s_cbranch_execz 3 -> join",
+                                   "global_store_dwordx2 v[0:1], v[4:5], off", "join:", "s_or_b64 exec, exec, s[4:5]",
+                                   "v_accvgpr_write_b32 a4, v18", "s_endpgm"])
+    assert chk.walk(behind) == [], faulty_lines
+    uniform = body(["loop:",
+                    "s_and_saveexec_b64 s[4:5], vcc",
+                    "s_xor_b64 s[0:1], exec, s[4:5]",          # the saved mask changes its register
+                    "global_store_dwordx2 v[0:1], v[4:5], off",
+                    "s_or_b64 exec, exec, s[0:1]",
+                    "s_cmp_lt_i32 s8, s9",
+                    "s_cbranch_scc1 65500 -> loop",
+                    "v_accvgpr_write_b32 a4, v18",
+                    "s_endpgm"])
+    assert chk.walk(uniform) == []
+
+
 def test_no_kernel_of_the_library_uses_scratch():
     """Code-object metadata of every kernel in libmsnap.so: .private_segment_fixed_size == 0.  Spilled registers cost
     memory round trips inside the hot loops, and scratch ties a launch to per-queue state of the runtime (an order-9

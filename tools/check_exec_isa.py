@@ -152,7 +152,7 @@ def main():
     for obj in objs:
         n_kernels, n_spill, bad = check(obj)
         for k, ins, since in bad:
-            print(f"check_exec_isa: {os.path.basename(obj)}: {k}: `{ins}` under a reduced exec mask (after `{since}`)")
+            print(f"check_exec_isa: {os.path.basename(obj)}: {k}: `{ins}` under a reduced exec mask ({since})")
         if bad:
             rc = 1
         else:
