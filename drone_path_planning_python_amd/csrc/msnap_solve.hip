@@ -1763,10 +1763,13 @@ static int launch_solve_k(msnap_ctx *ctx, int N, int M, const double *wp, const 
   // (order 7, tools/order_sizes.py with PROBE_ORDER=7, 10 segments: 4096 drones 7.4 us against 8.6 (small-batch
   //  kernel) and 11.0 (solve_kernel_reg); 8192: 8.9 / 12.8 / 12.9; 16 384: 13.4 / - / 16.2; 32 768: 21.6 / - / 22.1;
   //  65 536: 42.0 / - / 43.4 (eager launches); 2^20: 0.70 ms against 0.634 -- beyond 256 drones per CU the 16-drone
-  //  waves of solve_kernel_reg are ahead)
+  //  waves of solve_kernel_reg are ahead.  That holds for its two-waves-per-SIMD instance only: with 11..20 segments
+  //  solve_kernel_reg<4, 20> is one wave per SIMD and the column-split kernel stays ahead at every size -- 262 144 x 20:
+  //  335 against 370 us, 2^20 x 20: 1.357 against 1.407 ms (59 against 57 % of the HBM peak), 2^20 x 14: 0.941 against
+  //  1.020 ms (profiles/r04_order7_long.txt))
   const bool twin_ok = (M >= 4 && M <= (K == 5 ? kTwinMaxSeg : kTwinMaxSeg7) && !ctx->no_twin &&
                         (ctx->twin_max_drones > 0 ? N <= ctx->twin_max_drones
-                                                   : (K == 5 || N <= ctx->n_cu * 256)));
+                                                   : (K == 5 || N <= ctx->n_cu * 256 || M > kRegMaxSeg)));
   const int twist_max = ctx->twist_max_drones > 0 ? ctx->twist_max_drones
                                                   : ctx->n_cu * (twin_ok ? 1 : 4) * kTwistDrones;
   if (M >= 2 && M <= (K == 4 ? kTwistMaxSeg : kTwistMaxSeg9) && N <= twist_max && !ctx->no_twist) {

@@ -27,6 +27,8 @@ for N in sizes:
     st = torch.empty((N,), dtype=torch.int32, device=dev)
     bytes_ = N * (8 * 5 * (M + 1) + 8 * M * (1 + 4 * (order + 1)))
     grids = [{"solve_grid_waves": int(g)} for g in os.environ.get("PROBE_GRIDS", "").split()]
+    if os.environ.get("PROBE_TWIN_MAX"):      # the column-split kernel beyond the launcher's batch-size limit (order 7)
+        grids.append({"twin_max_drones": int(os.environ["PROBE_TWIN_MAX"])})
     for opts in [{}, {"no_twist": 1}, {"no_twist": 1, "no_twin": 1}] + grids:
         ctx = Context(0, order, 64)
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -50,6 +52,7 @@ for N in sizes:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 50 * 1e3
         tag = f" grid {opts['solve_grid_waves']}" if "solve_grid_waves" in opts else ""
+        tag = " (twin_max_drones)" if "twin_max_drones" in opts else tag
         print(f"order {order} {N:6d} x {M}: {ctx.last_kernel() + tag:40s} {us:7.2f} us = {bytes_ / us / 1e3 / 8000:.3f} of HBM peak "
               f"({N / us:.1f} traj/us)", flush=True)
         ctx.use_own_stream()
