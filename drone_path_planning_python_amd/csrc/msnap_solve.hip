@@ -421,6 +421,7 @@ __device__ __forceinline__ void store_segment_quad8(double *__restrict__ seg_bas
 }
 
 // dur[d][i] = t[d][i+1] - t[d][i] for the whole tile, one contiguous sweep
+template <int MAXCNT = 0>   // compile-time bound of drones x segments per tile (0: not known, scalar loop)
 __device__ __forceinline__ void store_durations(const double *sTraw, int shared_times, int tpitch, int M,
                                                 int nvalid, int lane, double *__restrict__ dur_tile) {
   // The trip count is WAVE-UNIFORM (a scalar loop around a predicated body), not `for (e = lane; e < cnt; e += 64)`:
@@ -430,14 +431,19 @@ __device__ __forceinline__ void store_durations(const double *sTraw, int shared_
   // they wrote no lane, the next tile's prefetch indices were garbage: "Memory access fault by GPU" (DESIGN.md 9.3;
   // tools/check_exec_isa.py now refuses a build with such a copy under a reduced exec mask)
   const int cnt = nvalid * M;
-  for (int e0 = 0; e0 < cnt; e0 += kWave) {
-    const int e = e0 + lane;
+  auto one = [&](int e) {
     if (e < cnt) {
       const int dl = e / M;
       const int i = e - dl * M;
       const double *lt = sTraw + (shared_times ? 0 : dl * tpitch);
       dur_tile[e] = lt[i + 1] - lt[i];
     }
+  };
+  if constexpr (MAXCNT > 0) {      // straight-line instances: two or three predicated rounds, no loop at all
+#pragma unroll
+    for (int e0 = 0; e0 < MAXCNT; e0 += kWave) one(e0 + lane);
+  } else {
+    for (int e0 = 0; e0 < cnt; e0 += kWave) one(e0 + lane);
   }
 }
 
@@ -1211,6 +1217,8 @@ solve_kernel_twin(const double *__restrict__ wp, const double *__restrict__ tt, 
     twin_stage_wait<M, 2 * kStoresPerSeg>(pre);
     twin_stage_store<M>(shared_times, nvalid, sWraw, sTraw, lane, pre);
     wave_lds_fence();
+    // (the scalar-loop form: with the rounds unrolled -- store_durations<kTwinDrones * M> -- the compiler put accumulation-register
+    //  copies of the 17..20-segment order-9 instances INSIDE a round's `if (e < cnt)`; tools/check_exec_isa.py refused that build)
     store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwinDrones * M);
 
     const int dloc = live ? dl : (N - 1 - tile * kTwinDrones);
@@ -1555,7 +1563,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     }
     __syncthreads();
     MSNAP_TL(1);
-    store_durations(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
+    store_durations<kTwistDrones * M>(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
 
     const int dloc = live ? dl : (N - 1 - tile * kTwistDrones);
     const double *lw = sWraw + dloc * wpitch + a;
