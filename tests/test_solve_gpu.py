@@ -273,8 +273,10 @@ def test_long_lived_context_after_many_short_lived_ones(ctx9, gold9):
     OWN stream has run small instances; fifteen short-lived contexts are created, run every kernel family of their
     segment count and are destroyed (streams, staging, bounce buffers and events freed each time); then the long-lived
     context launches, for the first time, the instances of 13..20 segments -- from host pointers, then from device
-    pointers on a borrowed torch stream.  Every result is checked; no kernel of the library uses scratch
-    (tests/test_abi.py), which is what the aborting build differed in."""
+    pointers on a borrowed torch stream.  Every result is checked.  (Round 4 found what the abort was: a GPU memory
+    fault whose message pytest's fd capture had swallowed, caused by compiler-placed spill copies under exec == 0 behind
+    a loop with a divergent trip count -- DESIGN.md 9.3; tools/check_exec_isa.py and
+    test_order9_long_paths_inside_a_guarded_arena are the guards, this sequence stays as the historical regression.)"""
     import torch
     from drone_path_planning_python_amd import Context
     from drone_path_planning_python_amd.synthetic import swarm
