@@ -45,7 +45,12 @@ def disassemble(obj):
         subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                         f"--input={fat}", f"--output={co}"], check=True)
         text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout
-    return subprocess.run(["c++filt"], input=text, capture_output=True, text=True).stdout
+    for filt in ("c++filt", f"{LLVM}/llvm-cxxfilt"):      # readable kernel names; the check itself does not need them
+        try:
+            return subprocess.run([filt], input=text, capture_output=True, text=True, check=True).stdout
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    return text
 
 
 def kernels_of(text):
