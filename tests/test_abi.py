@@ -144,6 +144,15 @@ def test_the_exec_check_sees_the_round_4_fault_pattern():
                                    "global_store_dwordx2 v[0:1], v[4:5], off", "join:", "s_or_b64 exec, exec, s[4:5]",
                                    "v_accvgpr_write_b32 a4, v18", "s_endpgm"])
     assert chk.walk(behind) == [], faulty_lines
+    # the same placement with an ordinary register move (what a kernel without accumulation registers would get): behind
+    # the latch of a loop that runs until no lane is left, exec is zero on every execution -- any vector instruction there
+    # is reported
+    moved = body([ln.replace("v_accvgpr_write_b32 a4, v18", "v_mov_b32_e32 v40, v18").replace("v_accvgpr_write_b32 a2, v22", "s_nop 0")
+                  for ln in ["s_and_saveexec_b64 s[4:5], s[0:1]", "s_cbranch_execz 58 -> join", "loop:",
+                             "global_store_dwordx2 v[0:1], v[4:5], off", "s_andn2_b64 exec, exec, s[6:7]",
+                             "s_cbranch_execnz 65501 -> loop", "v_accvgpr_write_b32 a4, v18", "v_accvgpr_write_b32 a2, v22",
+                             "join:", "s_or_b64 exec, exec, s[4:5]", "v_mov_b32_e32 v41, v18", "s_endpgm"]])
+    assert [f[0] for f in chk.walk(moved)] == ["v_mov_b32_e32 v40, v18"]
     uniform = body(["loop:",
                     "s_and_saveexec_b64 s[4:5], vcc",
                     "s_xor_b64 s[0:1], exec, s[4:5]",          # the saved mask changes its register

@@ -13,6 +13,9 @@ The check walks every kernel's control-flow graph with an abstract exec state: `
 pair that holds the wider mask, `s_or_b64 exec, exec, pair` pops down to it, `s_andn2_b64 exec, exec, ..` (lanes
 leaving a loop) marks the mask narrow until the next restore.  A copy reached with a non-empty stack or a narrow mask
 is reported.  Conservative: a copy of a value that lives only inside a divergent region would be reported too.
+Second rule, for kernels without such copies (an ordinary v_mov placed the same way looks like any other move): behind
+the latch of a loop that runs until no lane is left (`s_cbranch_execnz` backwards) exec is zero on EVERY execution until
+it is written again, so any vector instruction there is reported -- it can only be one the compiler misplaced.
 
     python tools/check_exec_isa.py [object files ...]        (default: csrc/msnap_solve.o msnap_aux.o msnap_grid.o)
 """
@@ -35,6 +38,8 @@ OR_EXEC = re.compile(rf"^s_or_b64 exec, exec, {PAIR}")
 ALIAS = re.compile(rf"^s_(?:xor_b64 {PAIR}, exec, {PAIR}|mov_b64 {PAIR}, {PAIR})$")    # the saved mask changes its register
 MOV_EXEC = re.compile(rf"^s_mov_b64 exec, (\S+)")
 NARROW = re.compile(r"^s_(?:andn2|and)_b64 exec, exec,")       # lanes leave (loops with a divergent trip count)
+EXEC_WRITE = re.compile(r"^s_\w+_saveexec_b64|^s_\w+ exec\b|^v_cmpx")
+VECTOR = re.compile(r"^(v_(?!readlane|readfirstlane|writelane)|ds_|global_|flat_|buffer_|scratch_)")
 OTHER_EXEC = re.compile(r"^s_\w+ exec\b|^v_cmpx")               # any other writer of exec: treated as narrowing
 
 
@@ -79,17 +84,24 @@ def walk(body):
     control flow as LLVM emits it: s_*_saveexec pushes, `s_or_b64 exec, exec, pair` pops down to that pair.
     Returns the list of (instruction, state) for register-pressure copies executed with a possibly reduced mask."""
     at = {addr: i for i, (_, addr, _) in enumerate(body)}
-    seen, bad, work = set(), [], [(0, (), False)]
+    seen, bad, work = set(), [], [(0, (), False, False)]
     while work:
-        i, stack, narrow = work.pop()
+        i, stack, narrow, zero = work.pop()
         while i < len(body):
-            key = (i, stack, narrow)
+            key = (i, stack, narrow, zero)
             if key in seen:
                 break
             seen.add(key)
             ins, _, target = body[i]
             if SPILL.match(ins) and (stack or narrow):
                 bad.append((ins, stack, narrow))
+            elif zero and VECTOR.match(ins):
+                # exec is zero here on every execution (behind the latch of a loop that runs until no lane is left, no
+                # write of exec since): a vector instruction does nothing -- if the compiler put one here it believes
+                # otherwise (the copies of round 4 sat exactly here)
+                bad.append((ins, ("<exec == 0>",), False))
+            if EXEC_WRITE.match(ins):
+                zero = False
             m = PUSH.match(ins)
             if m:       # (the same pair again: the else flip of an if, or the region re-entered in a loop)
                 pair = m.group(1)
@@ -129,9 +141,11 @@ def walk(body):
                 i = at[target]
                 continue
             if op.startswith("s_cbranch") and target is not None and target in at:
-                work.append((at[target], stack, narrow))
+                work.append((at[target], stack, narrow, zero))
+                if op == "s_cbranch_execnz" and at[target] <= i:      # the latch of a loop the lanes leave one by one:
+                    zero = True                                        # behind it exec is zero on EVERY execution
             i += 1
-    visited = {i for i, _, _ in seen}
+    visited = {i for i, _, _, _ in seen}
     missed = [body[i][0] for i in range(len(body)) if i not in visited and SPILL.match(body[i][0])]
     if missed:      # a copy the walk never reached: the graph was not understood -- report rather than pass
         bad.append((missed[0], ("<unreached>",), False))
