@@ -1514,7 +1514,17 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
 #pragma unroll
   for (int r = 0; r < NU; ++r) dsg[r] = (r & 1) ? 1.0 : -1.0;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // ONE tile per wave, no tile loop: the launcher starts exactly one wave per tile (launch_solve_k: grid = nt8).  With
+  // a loop around the body the compiler hoisted ~130 loop-invariant instructions (constants, lane-derived indices) into
+  // its preheader -- IN FRONT of the tile's input loads, a quarter of a microsecond of a 3.6 us kernel (round 4)
+  // (and no `tile < ntiles` test: it made the kernel fetch `ntiles` alone, wait, branch, and only then fetch its other
+  //  arguments -- two dependent scalar-cache round trips in front of the first load; gridDim.x == ntiles by construction)
+  const int tile = blockIdx.x;
+  (void)ntiles;
+  // (pinning the three output pointers in SGPRs at the top -- the compiler re-fetches each right in front of its first
+  //  use, a scalar-cache hit on the dependent chain -- was measured and LOST: 4.52 against 4.38 us per step; the kernel
+  //  holds ~60 fp64 constants in scalar registers and six more live ones push some of them out)
+  {
 #ifdef MSNAP_TOOLS_TIMELINE
     const int tl_tile = tile;
 #endif
@@ -1525,7 +1535,6 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     const int left = N - tile * kTwistDrones;
     const int nvalid = left < kTwistDrones ? left : kTwistDrones;
 
-    if (tile != (int)blockIdx.x) __syncthreads();
     {   // stage the 8 drones' inputs (one flight)
       const double2 *wsrc = reinterpret_cast<const double2 *>(wp + (size_t)tile * kTwistDrones * wpitch);
       double2 *wdst = reinterpret_cast<double2 *>(sWraw);
@@ -1563,7 +1572,6 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     }
     __syncthreads();
     MSNAP_TL(1);
-    store_durations<kTwistDrones * M>(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
 
     const int dloc = live ? dl : (N - 1 - tile * kTwistDrones);
     const double *lw = sWraw + dloc * wpitch + a;
@@ -1683,7 +1691,7 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
     const bool f_time = ((__ballot(badtime) >> gsh) & 0xFFull) != 0;
     const bool f_sing = ((__ballot(singular) >> gsh) & 0xFFull) != 0;
     const int st = f_nonfinite ? MSNAP_ST_NONFINITE : f_time ? MSNAP_ST_TIMES : f_sing ? MSNAP_ST_SINGULAR : MSNAP_ST_OK;
-    if (live && (lane & 7) == 0) status[d] = st;
+    if (live && (lane & 7) == 0) status[d] = st;      // (moved to the end with the durations: no gain, 4.30 against 4.28 us)
     const bool bad = st != 0;
 
     MSNAP_TL(3);
@@ -1743,6 +1751,10 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
       }
       if constexpr (MAXH * NU >= 3 * kTwistFenceHalf) __builtin_amdgcn_sched_barrier(0);
     }
+    // the durations leave LAST: in front of the sweeps they cost the fetch of their pointer and ~40 instructions on the
+    // dependent chain; the staged times are still in LDS (the z stash lives behind them, nothing aliases the inputs)
+    __builtin_amdgcn_sched_barrier(0);
+    store_durations<kTwistDrones * M>(sTraw, shared_times, tpitch, M, nvalid, lane, dur + (size_t)tile * kTwistDrones * M);
     MSNAP_TL(4);
   }
 }
