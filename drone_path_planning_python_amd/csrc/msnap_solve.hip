@@ -1742,6 +1742,8 @@ solve_kernel_twist(const double *__restrict__ wp, const double *__restrict__ tt,
         // the batch end mirror drone N-1 (same inputs, same values, same addresses), so the stores
         // need no predicate and the sweep stays one basic block.
         {
+          // (a lane base formed early and pinned in two vector registers, so that the fetch of `coef` leaves the
+          //  dependent chain, was measured: 4.54 against 4.28 us per step -- not shipped)
           double *o = coef + (((size_t)d * M + seg) * 4 + a) * NC;
 #pragma unroll
           for (int m = 0; m < NC; m += 2) *reinterpret_cast<double2 *>(o + m) = make_double2(c[m], c[m + 1]);
